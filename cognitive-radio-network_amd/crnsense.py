@@ -1,0 +1,184 @@
+"""ctypes binding of libcrnsense's C ABI (include/crn_sense.h).
+
+Plumbing for tests/, bench.py and __graft_entry__.py only: the product is the C-ABI shared
+library and the C++ engine in host/; nothing here computes.  There is no CPU fallback: loading
+fails loudly when libcrnsense.so has not been built, and crn_sense_create fails when no GPU is
+visible.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcrnsense.so")
+
+CRN_ABI_VERSION = 1
+CRN_MAX_BANDS = 80
+CRN_MAX_SEGS = 160
+
+MODE_REF_MAG, MODE_ENERGY = 0, 1
+DECIDE_ANN, DECIDE_THRESHOLD, DECIDE_NONE = 0, 1, 2
+WINDOW_RECT, WINDOW_HANN = 0, 1
+
+# every symbol include/crn_sense.h declares (tests check the library exports them all)
+EXPORTS = [
+    "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
+    "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
+    "crn_synth_fill_device", "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_last_error", "crn_abi_version",
+]
+
+
+class BandSeg(C.Structure):
+    _fields_ = [("lo", C.c_int32), ("hi", C.c_int32), ("band", C.c_int32)]
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("fft_len", C.c_int32), ("frames_per_epoch", C.c_int32),
+        ("hop", C.c_int32), ("mode", C.c_int32), ("decide", C.c_int32), ("window", C.c_int32),
+        ("n_bands", C.c_int32), ("n_segs", C.c_int32), ("ref_band", C.c_int32),
+        ("device", C.c_int32), ("reserved0", C.c_int32),
+        ("segs", BandSeg * CRN_MAX_SEGS),
+        ("thresh", C.c_float * CRN_MAX_BANDS),
+        ("ann_w_ih", (C.c_double * 6) * 5),
+        ("ann_w_ho", (C.c_double * 4) * 6),
+        ("ann_threshold", C.c_double),
+        ("tx_freq_for_decision", C.c_double * 4),
+    ]
+
+
+class Out(C.Structure):
+    _fields_ = [("features", C.c_void_p), ("ann_out", C.c_void_p), ("decision", C.c_void_p),
+                ("occupancy", C.c_void_p), ("spectrum", C.c_void_p)]
+
+
+class CrnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libcrnsense.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CrnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.crn_last_error.restype = C.c_char_p
+        L.crn_cfg_reference.argtypes = [C.POINTER(Cfg)]
+        L.crn_cfg_energy_scaled.argtypes = [C.POINTER(Cfg), C.c_int32, C.c_float]
+        L.crn_cfg_welch.argtypes = [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32]
+        L.crn_sense_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_void_p)]
+        L.crn_sense_destroy.argtypes = [C.c_void_p]
+        L.crn_sense_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                           C.POINTER(Out), C.c_void_p]
+        L.crn_sense_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                         C.POINTER(Out)]
+        L.crn_synth_fill_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
+                                            C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+        L.crn_sense_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CrnError(f"{what} failed ({rc}): {lib().crn_last_error().decode()}")
+
+
+def cfg_reference():
+    c = Cfg()
+    check(lib().crn_cfg_reference(C.byref(c)), "crn_cfg_reference")
+    return c
+
+
+def cfg_energy_scaled(fft_len, lam=4.0):
+    c = Cfg()
+    check(lib().crn_cfg_energy_scaled(C.byref(c), fft_len, lam), "crn_cfg_energy_scaled")
+    return c
+
+
+def cfg_welch(fft_len, frames_per_epoch, n_bands):
+    c = Cfg()
+    check(lib().crn_cfg_welch(C.byref(c), fft_len, frames_per_epoch, n_bands), "crn_cfg_welch")
+    return c
+
+
+def samples_per_epoch(cfg, L=None):
+    """Dense epoch length in samples (the default epoch_stride)."""
+    L = cfg.fft_len if L is None else L
+    return cfg.frames_per_epoch * (L if cfg.hop == cfg.fft_len else cfg.hop)
+
+
+def samples_needed(cfg, n_epochs, L=None):
+    """Samples a dense buffer must hold for n_epochs (overlap adds a tail)."""
+    L = cfg.fft_len if L is None else L
+    tail = 0 if cfg.hop == cfg.fft_len else cfg.fft_len - cfg.hop
+    return n_epochs * samples_per_epoch(cfg, L) + tail
+
+
+class Sensor:
+    """Owns one crn_handle."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().crn_sense_create(C.byref(cfg), C.byref(self._h)), "crn_sense_create")
+
+    def close(self):
+        if self._h:
+            lib().crn_sense_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_variant(self, v):
+        check(lib().crn_sense_set_variant(self._h, v), "crn_sense_set_variant")
+
+    def kernel_info(self):
+        name = C.create_string_buffer(256)
+        thr, lds, epb = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().crn_sense_kernel_info(self._h, name, 256, C.byref(thr), C.byref(lds), C.byref(epb)),
+              "crn_sense_kernel_info")
+        return {"name": name.value.decode(), "threads_per_block": thr.value, "lds_bytes": lds.value,
+                "epochs_per_block": epb.value}
+
+    def run_device(self, iq_ptr, n_epochs, L, out_ptrs, stream=0, epoch_stride=0):
+        """iq_ptr / out_ptrs: raw device addresses (ints); out_ptrs keys are Out fields."""
+        o = Out(**{k: (v or None) for k, v in out_ptrs.items()})
+        check(lib().crn_sense_run_device(self._h, iq_ptr, n_epochs, L, epoch_stride, C.byref(o),
+                                         C.c_void_p(stream or None)), "crn_sense_run_device")
+
+    def run_host(self, iq, n_epochs, L=None, want_spectrum=False, epoch_stride=0):
+        """iq: numpy float32 array of interleaved samples. Returns dict of numpy outputs."""
+        import numpy as np
+        cfg = self.cfg
+        L = cfg.fft_len if L is None else L
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        res = {
+            "features": np.zeros((n_epochs, cfg.n_bands), np.float32),
+            "ann_out": np.zeros((n_epochs, 3), np.float64),
+            "decision": np.zeros((n_epochs,), np.int32),
+            "occupancy": np.zeros((n_epochs, cfg.n_bands), np.uint8),
+        }
+        if want_spectrum:
+            res["spectrum"] = np.zeros((n_epochs, cfg.fft_len), np.float32)
+        o = Out(**{k: v.ctypes.data for k, v in res.items()})
+        check(lib().crn_sense_run_host(self._h, iq.ctypes.data, n_epochs, L, epoch_stride, C.byref(o)),
+              "crn_sense_run_host")
+        return res
+
+    def synth_fill_device(self, iq_ptr, n_epochs, spe, seed, noise_power=1e-6, signal_rms=0.02,
+                          tones=8, truth_ptr=0, stream=0):
+        check(lib().crn_synth_fill_device(self._h, iq_ptr, n_epochs, spe, seed, noise_power, signal_rms,
+                                          tones, C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
+              "crn_synth_fill_device")

@@ -1,0 +1,343 @@
+// crn_api.cpp — the C ABI of libcrnsense (include/crn_sense.h): handle, device tables, launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crn_sense.h"
+#include "crn_internal.h"
+#include "crn_kernels.h"
+
+namespace crn {
+static thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+}  // namespace crn
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return crn::fail(CRN_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+  } while (0)
+
+struct crn_handle {
+  crn_cfg cfg;
+  int variant = 0;
+  // one device slab holding every table
+  void *d_tables = nullptr;
+  const float2 *d_tw1 = nullptr, *d_tw2 = nullptr;
+  const float *d_window = nullptr, *d_thresh = nullptr;
+  const int *d_band_seg_begin = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
+  const int *d_band_bins_begin = nullptr, *d_band_bins = nullptr;
+  const double *d_wih = nullptr, *d_who = nullptr;
+  // scratch of crn_sense_run_host
+  void *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace {
+
+bool supported_n(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; }
+
+int validate(const crn_cfg *c) {
+  if (!c) return crn::fail(CRN_ERR_ARG, "null cfg");
+  if (c->abi_version != CRN_ABI_VERSION) return crn::fail(CRN_ERR_ARG, "cfg.abi_version mismatch");
+  if (!supported_n(c->fft_len)) return crn::fail(CRN_ERR_ARG, "fft_len must be 512, 1024, 2048 or 4096");
+  if (c->frames_per_epoch < 1) return crn::fail(CRN_ERR_ARG, "frames_per_epoch < 1");
+  if (c->hop < 1 || c->hop > c->fft_len) return crn::fail(CRN_ERR_ARG, "hop out of range");
+  if (c->mode != CRN_MODE_REF_MAG && c->mode != CRN_MODE_ENERGY) return crn::fail(CRN_ERR_ARG, "bad mode");
+  if (c->decide < CRN_DECIDE_ANN || c->decide > CRN_DECIDE_NONE) return crn::fail(CRN_ERR_ARG, "bad decide");
+  if (c->window != CRN_WINDOW_RECT && c->window != CRN_WINDOW_HANN) return crn::fail(CRN_ERR_ARG, "bad window");
+  if (c->n_bands < 1 || c->n_bands > CRN_MAX_BANDS) return crn::fail(CRN_ERR_ARG, "n_bands out of range");
+  if (c->n_segs < 1 || c->n_segs > CRN_MAX_SEGS) return crn::fail(CRN_ERR_ARG, "n_segs out of range");
+  for (int s = 0; s < c->n_segs; s++) {
+    const crn_band_seg &g = c->segs[s];
+    if (g.lo < 0 || g.hi > c->fft_len || g.lo > g.hi || g.band < 0 || g.band >= c->n_bands)
+      return crn::fail(CRN_ERR_ARG, "band segment " + std::to_string(s) + " out of range");
+  }
+  if (c->decide == CRN_DECIDE_ANN && c->n_bands != 4)
+    return crn::fail(CRN_ERR_ARG, "DECIDE_ANN needs exactly 4 bands {NF, CH1, CH2, CH3}");
+  if (c->decide == CRN_DECIDE_THRESHOLD && c->ref_band >= c->n_bands)
+    return crn::fail(CRN_ERR_ARG, "ref_band out of range");
+  return CRN_OK;
+}
+
+// exp(-2 pi j q / n) with the angle index reduced exactly and the trig done in double.
+float2 twiddle(long long q, int n) {
+  q %= n;
+  const double ang = -2.0 * M_PI * (double)q / (double)n;
+  return make_float2((float)std::cos(ang), (float)std::sin(ang));
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+const char *crn_last_error(void) { return crn::g_err.c_str(); }
+int crn_abi_version(void) { return CRN_ABI_VERSION; }
+
+int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
+  if (!out) return crn::fail(CRN_ERR_ARG, "crn_sense_create: null out");
+  *out = nullptr;
+  if (int rc = validate(cfg)) return rc;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return crn::fail(CRN_ERR_DEVICE, "no HIP device visible (libcrnsense has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return crn::fail(CRN_ERR_ARG, "cfg.device out of range");
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  crn_handle *h = new (std::nothrow) crn_handle();
+  if (!h) return crn::fail(CRN_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+
+  const int N = cfg->fft_len, R3 = N / 256, T = N / 16;
+  std::vector<float2> tw1((size_t)16 * T), tw2((size_t)16 * R3);
+  for (int i = 0; i < 16; i++)
+    for (int t = 0; t < T; t++) tw1[(size_t)i * T + t] = twiddle((long long)i * t, N);
+  for (int i = 0; i < 16; i++)
+    for (int m = 0; m < R3; m++) tw2[(size_t)i * R3 + m] = twiddle((long long)i * m, T);
+  std::vector<float> win(N, 1.0f);
+  if (cfg->window == CRN_WINDOW_HANN)
+    for (int n = 0; n < N; n++) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)N));
+
+  // segments grouped by band, table order kept inside a band (the reference sums CH1's two runs
+  // in table order, CE_Predictive_Node.cpp:173-179)
+  std::vector<int> seg_begin(cfg->n_bands + 1, 0), seg_lo, seg_hi, bins_begin(cfg->n_bands + 1, 0), bins;
+  for (int b = 0; b < cfg->n_bands; b++) {
+    seg_begin[b] = (int)seg_lo.size();
+    bins_begin[b] = (int)bins.size();
+    for (int s = 0; s < cfg->n_segs; s++)
+      if (cfg->segs[s].band == b) {
+        seg_lo.push_back(cfg->segs[s].lo);
+        seg_hi.push_back(cfg->segs[s].hi);
+        for (int k = cfg->segs[s].lo; k < cfg->segs[s].hi; k++) bins.push_back(k);
+      }
+  }
+  seg_begin[cfg->n_bands] = (int)seg_lo.size();
+  bins_begin[cfg->n_bands] = (int)bins.size();
+  if (bins.empty()) bins.push_back(0);
+
+  struct Piece { const void *src; size_t bytes; size_t off; };
+  std::vector<Piece> pieces = {
+      {tw1.data(), tw1.size() * sizeof(float2), 0},
+      {tw2.data(), tw2.size() * sizeof(float2), 0},
+      {win.data(), win.size() * sizeof(float), 0},
+      {cfg->thresh, sizeof(float) * CRN_MAX_BANDS, 0},
+      {seg_begin.data(), seg_begin.size() * sizeof(int), 0},
+      {seg_lo.data(), seg_lo.size() * sizeof(int), 0},
+      {seg_hi.data(), seg_hi.size() * sizeof(int), 0},
+      {bins_begin.data(), bins_begin.size() * sizeof(int), 0},
+      {bins.data(), bins.size() * sizeof(int), 0},
+      {cfg->ann_w_ih, sizeof(cfg->ann_w_ih), 0},
+      {cfg->ann_w_ho, sizeof(cfg->ann_w_ho), 0},
+  };
+  size_t total = 0;
+  for (auto &p : pieces) {
+    p.off = total;
+    total = align_up(total + p.bytes, 256);
+  }
+  std::vector<char> host(total, 0);
+  for (auto &p : pieces) std::memcpy(host.data() + p.off, p.src, p.bytes);
+  hipError_t e = hipMalloc(&h->d_tables, total);
+  if (e != hipSuccess) {
+    delete h;
+    return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(tables): ") + hipGetErrorString(e));
+  }
+  e = hipMemcpy(h->d_tables, host.data(), total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(h->d_tables);
+    delete h;
+    return crn::fail(CRN_ERR_DEVICE, std::string("hipMemcpy(tables): ") + hipGetErrorString(e));
+  }
+  char *base = static_cast<char *>(h->d_tables);
+  h->d_tw1 = reinterpret_cast<const float2 *>(base + pieces[0].off);
+  h->d_tw2 = reinterpret_cast<const float2 *>(base + pieces[1].off);
+  h->d_window = reinterpret_cast<const float *>(base + pieces[2].off);
+  h->d_thresh = reinterpret_cast<const float *>(base + pieces[3].off);
+  h->d_band_seg_begin = reinterpret_cast<const int *>(base + pieces[4].off);
+  h->d_seg_lo = reinterpret_cast<const int *>(base + pieces[5].off);
+  h->d_seg_hi = reinterpret_cast<const int *>(base + pieces[6].off);
+  h->d_band_bins_begin = reinterpret_cast<const int *>(base + pieces[7].off);
+  h->d_band_bins = reinterpret_cast<const int *>(base + pieces[8].off);
+  h->d_wih = reinterpret_cast<const double *>(base + pieces[9].off);
+  h->d_who = reinterpret_cast<const double *>(base + pieces[10].off);
+  *out = h;
+  return CRN_OK;
+}
+
+int crn_sense_destroy(crn_handle *h) {
+  if (!h) return CRN_OK;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (h->d_tables) (void)hipFree(h->d_tables);
+  delete h;
+  return CRN_OK;
+}
+
+int crn_sense_set_variant(crn_handle *h, int32_t variant) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  if (variant < 0 || variant > 8) return crn::fail(CRN_ERR_ARG, "variant must be 0..8");
+  h->variant = variant;
+  return CRN_OK;
+}
+
+int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *threads_per_block,
+                          int32_t *lds_bytes, int32_t *epochs_per_block) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  int thr = 0, lds = 0, epb = 0;
+  crn::sense_geometry(h->cfg.fft_len, h->variant, &thr, &lds, &epb);
+  if (threads_per_block) *threads_per_block = thr;
+  if (lds_bytes) *lds_bytes = lds;
+  if (epochs_per_block) *epochs_per_block = epb;
+  if (name && name_len > 0) {
+    int nbuf = 1, pf = 0, nt = 0;
+    crn::sense_variant(h->cfg.fft_len, h->variant, &nbuf, &pf, &nt);
+    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,MAG=%d,WIN=%d>",
+                  h->cfg.fft_len / 256, nbuf, pf, nt,
+                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT);
+  }
+  return CRN_OK;
+}
+
+static int resolve_strides(const crn_handle *h, int32_t L, int64_t *epoch_stride, int *frame_stride) {
+  const crn_cfg &c = h->cfg;
+  if (L < 1 || L > c.fft_len)
+    return crn::fail(CRN_ERR_ARG, "samples_per_frame must be in 1..fft_len (the reference's unchecked memcpy, "
+                                   "CE_Predictive_Node.cpp:149, is rejected here)");
+  if (c.hop != c.fft_len && L != c.fft_len)
+    return crn::fail(CRN_ERR_ARG, "overlapped frames (hop < fft_len) need samples_per_frame == fft_len");
+  *frame_stride = c.hop == c.fft_len ? L : c.hop;
+  if (*epoch_stride <= 0) *epoch_stride = (int64_t)c.frames_per_epoch * *frame_stride;
+  return CRN_OK;
+}
+
+int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                         int64_t epoch_stride, const crn_out *d_out, void *stream) {
+  if (!h || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / outputs");
+  if (n_epochs < 0) return crn::fail(CRN_ERR_ARG, "n_epochs < 0");
+  if (n_epochs == 0) return CRN_OK;
+  if (!d_iq) return crn::fail(CRN_ERR_ARG, "null IQ pointer");
+  if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) != 0) return crn::fail(CRN_ERR_ARG, "IQ pointer must be 8-byte aligned");
+  int frame_stride = 0;
+  if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
+  if (n_epochs > (int64_t)0x7fffffff * 1) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
+  const crn_cfg &c = h->cfg;
+  crn::SenseParams p{};
+  p.iq = reinterpret_cast<const float2 *>(d_iq);
+  p.n_epochs = n_epochs;
+  p.epoch_stride = epoch_stride;
+  p.frame_stride = frame_stride;
+  p.L = samples_per_frame;
+  p.K = c.frames_per_epoch;
+  p.tw1 = h->d_tw1;
+  p.tw2 = h->d_tw2;
+  p.window = h->d_window;
+  p.band_seg_begin = h->d_band_seg_begin;
+  p.seg_lo = h->d_seg_lo;
+  p.seg_hi = h->d_seg_hi;
+  p.thresh = h->d_thresh;
+  p.ann_w_ih = h->d_wih;
+  p.ann_w_ho = h->d_who;
+  p.ann_threshold = c.ann_threshold;
+  p.n_bands = c.n_bands;
+  p.decide = c.decide;
+  p.ref_band = c.ref_band;
+  p.features = d_out->features;
+  p.ann_out = c.decide == CRN_DECIDE_ANN ? d_out->ann_out : nullptr;
+  p.decision = d_out->decision;
+  p.occupancy = d_out->occupancy;
+  p.spectrum = d_out->spectrum;
+  HIP_TRY(crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT,
+                            h->variant, static_cast<hipStream_t>(stream)));
+  return CRN_OK;
+}
+
+int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t samples_per_frame,
+                       int64_t epoch_stride, const crn_out *out) {
+  if (!h || !out) return crn::fail(CRN_ERR_ARG, "null handle / outputs");
+  if (n_epochs < 0) return crn::fail(CRN_ERR_ARG, "n_epochs < 0");
+  if (n_epochs == 0) return CRN_OK;
+  if (!iq) return crn::fail(CRN_ERR_ARG, "null IQ pointer");
+  int frame_stride = 0;
+  if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
+  const crn_cfg &c = h->cfg;
+  HIP_TRY(hipSetDevice(c.device));
+  // samples touched: last epoch start + (K-1) frame strides + the last frame
+  const int64_t last_frame = c.hop == c.fft_len ? samples_per_frame : c.fft_len;
+  const size_t n_samples = (size_t)((n_epochs - 1) * epoch_stride + (int64_t)(c.frames_per_epoch - 1) * frame_stride + last_frame);
+  const size_t b_iq = align_up(n_samples * 8, 256);
+  const size_t b_feat = align_up((size_t)n_epochs * c.n_bands * sizeof(float), 256);
+  const size_t b_ann = align_up((size_t)n_epochs * 3 * sizeof(double), 256);
+  const size_t b_dec = align_up((size_t)n_epochs * sizeof(int32_t), 256);
+  const size_t b_occ = align_up((size_t)n_epochs * c.n_bands, 256);
+  const size_t b_spec = out->spectrum ? align_up((size_t)n_epochs * c.fft_len * sizeof(float), 256) : 0;
+  const size_t need = b_iq + b_feat + b_ann + b_dec + b_occ + b_spec;
+  if (need > h->scratch_bytes) {
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    h->d_scratch = nullptr;
+    h->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&h->d_scratch, need);
+    if (e != hipSuccess) return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    h->scratch_bytes = need;
+  }
+  char *b = static_cast<char *>(h->d_scratch);
+  float *d_iq = reinterpret_cast<float *>(b);
+  crn_out d{};
+  d.features = reinterpret_cast<float *>(b + b_iq);
+  d.ann_out = reinterpret_cast<double *>(b + b_iq + b_feat);
+  d.decision = reinterpret_cast<int32_t *>(b + b_iq + b_feat + b_ann);
+  d.occupancy = reinterpret_cast<uint8_t *>(b + b_iq + b_feat + b_ann + b_dec);
+  d.spectrum = out->spectrum ? reinterpret_cast<float *>(b + b_iq + b_feat + b_ann + b_dec + b_occ) : nullptr;
+  hipStream_t s = nullptr;
+  HIP_TRY(hipMemcpyAsync(d_iq, iq, n_samples * 8, hipMemcpyHostToDevice, s));
+  if (int rc = crn_sense_run_device(h, d_iq, n_epochs, samples_per_frame, epoch_stride, &d, s)) return rc;
+  if (out->features) HIP_TRY(hipMemcpyAsync(out->features, d.features, (size_t)n_epochs * c.n_bands * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (out->ann_out && c.decide == CRN_DECIDE_ANN) HIP_TRY(hipMemcpyAsync(out->ann_out, d.ann_out, (size_t)n_epochs * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (out->decision) HIP_TRY(hipMemcpyAsync(out->decision, d.decision, (size_t)n_epochs * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (out->occupancy) HIP_TRY(hipMemcpyAsync(out->occupancy, d.occupancy, (size_t)n_epochs * c.n_bands, hipMemcpyDeviceToHost, s));
+  if (out->spectrum) HIP_TRY(hipMemcpyAsync(out->spectrum, d.spectrum, (size_t)n_epochs * c.fft_len * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return CRN_OK;
+}
+
+int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs, int64_t samples_per_epoch,
+                          uint64_t seed, float noise_power, float signal_rms, int32_t tones_per_band,
+                          int32_t *d_truth, void *stream) {
+  if (!h || !d_iq) return crn::fail(CRN_ERR_ARG, "null handle / IQ pointer");
+  if (n_epochs < 0 || samples_per_epoch < 1) return crn::fail(CRN_ERR_ARG, "bad sizes");
+  if (tones_per_band < 0 || noise_power < 0.f) return crn::fail(CRN_ERR_ARG, "bad signal parameters");
+  const crn_cfg &c = h->cfg;
+  crn::SynthParams p{};
+  p.iq = reinterpret_cast<float2 *>(d_iq);
+  p.n_epochs = n_epochs;
+  p.samples_per_epoch = samples_per_epoch;
+  p.seed = seed;
+  p.noise_sigma = std::sqrt(noise_power * 0.5f);
+  p.tones = tones_per_band;
+  p.tone_amp = tones_per_band > 0 ? signal_rms / std::sqrt((float)tones_per_band) : 0.f;
+  p.fft_len = c.fft_len;
+  if (c.ref_band >= 0 || c.decide == CRN_DECIDE_ANN) {  // {NF, CH1, ..}: band 0 is never driven
+    p.active_band0 = 1;
+    p.n_active = std::min(3, c.n_bands - 1);
+  } else {
+    p.active_band0 = 0;
+    p.n_active = c.n_bands;
+  }
+  if (tones_per_band == 0) p.n_active = 0;
+  p.band_bins_begin = h->d_band_bins_begin;
+  p.band_bins = h->d_band_bins;
+  p.truth = d_truth;
+  HIP_TRY(crn::launch_synth(p, static_cast<hipStream_t>(stream)));
+  return CRN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// crn_kernels.h — kernel parameter blocks shared by crn_kernels.hip and crn_api.cpp (internal).
+#ifndef CRN_KERNELS_H
+#define CRN_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crn {
+
+enum { CRN_DECIDE_ANN_K = 0, CRN_DECIDE_THRESHOLD_K = 1, CRN_DECIDE_NONE_K = 2 };  // == crn_decide
+
+struct SenseParams {
+  // input stream
+  const float2 *iq;        // device, interleaved complex fp32
+  long long n_epochs;
+  long long epoch_stride;  // samples between epoch starts
+  int frame_stride;        // samples between frame starts inside an epoch
+  int L;                   // samples taken per frame (zero-padded to N)
+  int K;                   // frames per epoch
+  // tables (device, built at crn_sense_create)
+  const float2 *tw1;       // [16][T]  W_N^{t a}
+  const float2 *tw2;       // [16][R3] W_T^{m c}
+  const float *window;     // [N] or null
+  const int *band_seg_begin;  // [n_bands + 1] into seg_lo/seg_hi (segments grouped by band)
+  const int *seg_lo;
+  const int *seg_hi;
+  const float *thresh;     // [n_bands]
+  const double *ann_w_ih;  // [5][6]
+  const double *ann_w_ho;  // [6][4]
+  double ann_threshold;
+  int n_bands;
+  int decide;
+  int ref_band;
+  // outputs (device, nullable)
+  float *features;
+  double *ann_out;
+  int32_t *decision;
+  uint8_t *occupancy;
+  float *spectrum;
+};
+
+struct SynthParams {
+  float2 *iq;
+  long long n_epochs;
+  long long samples_per_epoch;
+  unsigned long long seed;
+  float noise_sigma;  // per component
+  float tone_amp;     // per tone
+  int tones;
+  int fft_len;
+  int n_active;       // pick uniformly in 0..n_active (0 = idle)
+  int active_band0;   // first band index that can be picked
+  const int *band_bins_begin;  // [n_bands + 1]
+  const int *band_bins;        // flattened bin lists per band
+  int32_t *truth;              // [n_epochs] or null
+};
+
+hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
+                        hipStream_t stream);
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt);
+void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
+hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
+
+}  // namespace crn
+#endif

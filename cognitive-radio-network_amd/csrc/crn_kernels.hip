@@ -1,0 +1,561 @@
+// crn_kernels.hip — gfx950 (MI355X) kernels of the spectrum-sensing hot path.
+//
+// One launch runs, for n_epochs decision epochs of K frames each, the whole of
+//   cognitive_engines/CE_Predictive_Node/CE_Predictive_Node.cpp:148-261 (reference):
+//   zero-padded staging (:149) -> forward DFT (:150, liquid-dsp fft_execute) -> per-bin
+//   magnitude / energy running mean over K frames (:152-154) -> band sums (:173-191) ->
+//   features (:194-200) -> 4-5-3 sigmoid net in double (:214-235) -> decision cascade (:245-261).
+//
+// Shape of the computation (DESIGN.md has the derivation):
+//   N = 16 * 16 * R3 (R3 = 2, 4, 8, 16 -> N = 512 .. 4096).  A frame is handled by T = N/16
+//   threads, 16 complex points per thread, in three register passes:
+//     pass 1  radix-16 over r   : x[t + T r]            -> twiddle W_N^{t a}   -> LDS exchange 1
+//     pass 2  radix-16 over m_hi: y_a[R3 m_hi + m_lo]   -> twiddle W_T^{m_lo c}-> LDS exchange 2
+//     pass 3  radix-R3 over m_lo                        -> X[a + 16 c + 256 d] in registers
+//   Exchange 2 stays inside the R3 lanes that share `a` (same wave), so a 4096-point frame needs
+//   one s_barrier per frame (two with a single LDS buffer) and N <= 1024 needs none.
+//   HBM is read exactly once: 8 B per input sample, coalesced 512 B per wave instruction.
+//   |X|^2 (or |X|) is accumulated per bin in 16 registers per thread over the K frames; the band
+//   reduction, the net and the cascade run once per epoch from LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crn_kernels.h"
+
+namespace crn {
+
+// ---------------------------------------------------------------------------------------------
+// complex helpers (forward transform: W = exp(-j theta))
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+  return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
+}
+
+// 4-point forward DFT, natural order in and out.
+__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+  const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+  const float2 s13 = cadd(a1, a3), d13 = csub(a1, a3);
+  a0 = cadd(s02, s13);
+  a2 = csub(s02, s13);
+  a1 = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - j d13
+  a3 = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + j d13
+}
+
+__device__ __forceinline__ void dft2(float2 &a0, float2 &a1) {
+  const float2 s = cadd(a0, a1), d = csub(a0, a1);
+  a0 = s;
+  a1 = d;
+}
+
+#define CRN_C1 0.92387953251128674f  // cos(pi/8)
+#define CRN_S1 0.38268343236508977f  // sin(pi/8)
+#define CRN_H 0.70710678118654752f   // sqrt(1/2)
+
+__device__ __forceinline__ float2 mul_w8_1(float2 a) {  // * exp(-j pi/4) = (h, -h)
+  return make_float2(CRN_H * (a.x + a.y), CRN_H * (a.y - a.x));
+}
+__device__ __forceinline__ float2 mul_w8_3(float2 a) {  // * exp(-j 3pi/4) = (-h, -h)
+  return make_float2(CRN_H * (a.y - a.x), -CRN_H * (a.x + a.y));
+}
+__device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }  // * (-j)
+
+// 16-point forward DFT: in[r] -> out[a], both natural order, as 4 x 4 (two radix-4 levels).
+__device__ __forceinline__ void dft16(const float2 (&in)[16], float2 (&out)[16]) {
+  float2 y[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = in[i];
+  // level A: for each r0, DFT4 over r1 (index r = r0 + 4 r1); result a0 replaces r1
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0++) dft4(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+  // internal twiddles W16^{r0 a0}, element (r0, a0) sits at y[r0 + 4 a0]
+  y[1 + 4 * 1] = cmul(y[1 + 4 * 1], make_float2(CRN_C1, -CRN_S1));  // W16^1
+  y[1 + 4 * 2] = mul_w8_1(y[1 + 4 * 2]);                             // W16^2
+  y[1 + 4 * 3] = cmul(y[1 + 4 * 3], make_float2(CRN_S1, -CRN_C1));  // W16^3
+  y[2 + 4 * 1] = mul_w8_1(y[2 + 4 * 1]);                             // W16^2
+  y[2 + 4 * 2] = mul_mj(y[2 + 4 * 2]);                               // W16^4
+  y[2 + 4 * 3] = mul_w8_3(y[2 + 4 * 3]);                             // W16^6
+  y[3 + 4 * 1] = cmul(y[3 + 4 * 1], make_float2(CRN_S1, -CRN_C1));  // W16^3
+  y[3 + 4 * 2] = mul_w8_3(y[3 + 4 * 2]);                             // W16^6
+  y[3 + 4 * 3] = cmul(y[3 + 4 * 3], make_float2(-CRN_C1, CRN_S1));  // W16^9
+  // level B: for each a0, DFT4 over r0; result a1 replaces r0; X[a0 + 4 a1] = y[a1 + 4 a0]
+#pragma unroll
+  for (int a0 = 0; a0 < 4; a0++) dft4(y[4 * a0], y[4 * a0 + 1], y[4 * a0 + 2], y[4 * a0 + 3]);
+#pragma unroll
+  for (int a0 = 0; a0 < 4; a0++)
+#pragma unroll
+    for (int a1 = 0; a1 < 4; a1++) out[a0 + 4 * a1] = y[a1 + 4 * a0];
+}
+
+// 8-point forward DFT as 2 x 4.
+__device__ __forceinline__ void dft8(const float2 (&in)[8], float2 (&out)[8]) {
+  float2 y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) y[i] = in[i];
+  // r = r0 + 2 r1 (r0 < 2, r1 < 4): DFT4 over r1 -> a0 at y[r0 + 2 a0]
+  dft4(y[0], y[2], y[4], y[6]);
+  dft4(y[1], y[3], y[5], y[7]);
+  // twiddles W8^{r0 a0} for r0 = 1
+  y[1 + 2 * 1] = mul_w8_1(y[1 + 2 * 1]);
+  y[1 + 2 * 2] = mul_mj(y[1 + 2 * 2]);
+  y[1 + 2 * 3] = mul_w8_3(y[1 + 2 * 3]);
+  // DFT2 over r0 -> a1; X[a0 + 4 a1]
+#pragma unroll
+  for (int a0 = 0; a0 < 4; a0++) {
+    dft2(y[2 * a0], y[2 * a0 + 1]);
+    out[a0] = y[2 * a0];
+    out[a0 + 4] = y[2 * a0 + 1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------
+template <int R3>
+struct Geo {
+  static constexpr int N = 256 * R3;
+  static constexpr int T = 16 * R3;           // threads per frame
+  static constexpr int GROUPS = 256 / T;      // frame groups (epochs in flight) per workgroup
+  static constexpr int ROW = T + R3;          // padded row of exchange 1 ([a][t]), complex units
+  static constexpr int GROUP_CPLX = 16 * ROW; // one exchange buffer of one group
+  static constexpr int J = 16 / R3;           // pass-3 butterflies per thread
+  static constexpr bool XWAVE = (T > 64);     // exchange 1 crosses waves -> s_barrier needed
+  static constexpr int TEAM = T < 64 ? T : 64;
+};
+
+__host__ __device__ constexpr int spec_phys(int k) { return k + (k >> 4); }  // padded float index
+
+template <bool NT>
+__device__ __forceinline__ float2 ld_iq(const float2 *p) {
+  if constexpr (NT) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+    return make_float2(v.x, v.y);
+  } else {
+    return *p;
+  }
+}
+
+template <int R3, bool NT>
+__device__ __forceinline__ void load_frame(float2 (&u)[16], const float2 *fp, int t, int L, bool active) {
+  constexpr int T = Geo<R3>::T, N = Geo<R3>::N;
+  if (!active) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = make_float2(0.f, 0.f);
+    return;
+  }
+  if (L == N) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(fp + t + T * r);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int idx = t + T * r;
+      u[r] = idx < L ? ld_iq<NT>(fp + idx) : make_float2(0.f, 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sensing kernel
+//   R3       N = 256 * R3
+//   NBUF     LDS exchange buffers (2 drops the second barrier per frame when T > 64)
+//   PREFETCH issue frame f+1's HBM loads before computing frame f
+//   NT       nontemporal loads for the IQ stream
+//   MAG      true: CRN_MODE_REF_MAG (|X|/K accumulate, feature = M^2); false: CRN_MODE_ENERGY
+//   WIN      multiply by the window table
+// ---------------------------------------------------------------------------------------------
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool MAG, bool WIN, int OCC>
+__global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
+  using G = Geo<R3>;
+  constexpr int T = G::T, N = G::N, ROW = G::ROW, J = G::J;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+  const int tid = threadIdx.x;
+  const int grp = tid / T;
+  const int t = tid % T;       // pass-1 column, n_lo
+  const int a = t / R3;        // pass-2/3 sub-transform id (k mod 16)
+  const int m_lo = t % R3;     // pass-2 column / pass-3 slot g
+  const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
+  const bool active = epoch < p.n_epochs;
+
+  float2 *gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+
+  // frame-invariant twiddles, kept in registers across the K frames
+  float2 tw1[16], tw2[16];
+#pragma unroll
+  for (int i = 1; i < 16; i++) {
+    tw1[i] = p.tw1[i * T + t];        // W_N^{t i}
+    tw2[i] = p.tw2[i * R3 + m_lo];    // W_T^{m_lo i}
+  }
+  float win[16];
+  if constexpr (WIN) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) win[r] = p.window[t + T * r];
+  }
+
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+
+  const float2 *ep = p.iq + (active ? epoch * p.epoch_stride : 0);
+  const int K = p.K;
+  const float Kf = (float)K;
+
+  float2 u[16], nx[16];
+  load_frame<R3, NT>(u, ep, t, p.L, active);
+
+  for (int f = 0; f < K; f++) {
+    if constexpr (PREFETCH) {
+      if (f + 1 < K) load_frame<R3, NT>(nx, ep + (long long)(f + 1) * p.frame_stride, t, p.L, active);
+    }
+    float2 *buf = gbuf + (NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
+
+    if constexpr (WIN) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) u[r] = make_float2(u[r].x * win[r], u[r].y * win[r]);
+    }
+
+    // ---- pass 1: DFT16 over r, twiddle W_N^{t a} ----
+    float2 v[16];
+    dft16(u, v);
+#pragma unroll
+    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], tw1[i]);
+
+    // ---- exchange 1: [a][t] ----
+    if constexpr (G::XWAVE && NBUF == 1) __syncthreads();  // rows may still be read as exchange 2
+#pragma unroll
+    for (int i = 0; i < 16; i++) buf[i * ROW + t] = v[i];
+    if constexpr (G::XWAVE) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    float2 *row = buf + a * ROW;
+#pragma unroll
+    for (int i = 0; i < 16; i++) u[i] = row[R3 * i + m_lo];
+
+    // ---- pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c} ----
+    dft16(u, v);
+#pragma unroll
+    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], tw2[i]);
+
+    // ---- exchange 2 (inside the R3 lanes sharing `a`): slot (c, m) at c*R3 + m + c/J ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; c++) row[c * R3 + m_lo + c / J] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // thread (a, g = m_lo) takes c = g*J + j, all m
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+      for (int m = 0; m < R3; m++) u[j * R3 + m] = row[(m_lo * J + j) * R3 + m + m_lo];
+
+    // ---- pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d at v[j*R3 + d] ----
+    if constexpr (R3 == 16) {
+      dft16(u, v);
+    } else if constexpr (R3 == 8) {
+#pragma unroll
+      for (int j = 0; j < J; j++) {
+        float2 in8[8], out8[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) in8[m] = u[j * 8 + m];
+        dft8(in8, out8);
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[j * 8 + m] = out8[m];
+      }
+    } else if constexpr (R3 == 4) {
+#pragma unroll
+      for (int j = 0; j < J; j++) {
+        dft4(u[j * 4], u[j * 4 + 1], u[j * 4 + 2], u[j * 4 + 3]);
+#pragma unroll
+        for (int m = 0; m < 4; m++) v[j * 4 + m] = u[j * 4 + m];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < J; j++) {
+        dft2(u[j * 2], u[j * 2 + 1]);
+        v[j * 2] = u[j * 2];
+        v[j * 2 + 1] = u[j * 2 + 1];
+      }
+    }
+
+    // ---- per-bin accumulate over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K) ----
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if constexpr (MAG) {
+        const float mag = __fsqrt_rn(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+        acc[i] += __fdiv_rn(mag, Kf);
+      } else {
+        acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, acc[i]));
+      }
+    }
+
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) u[r] = nx[r];
+    } else {
+      if (f + 1 < K) load_frame<R3, NT>(u, ep + (long long)(f + 1) * p.frame_stride, t, p.L, active);
+    }
+  }
+
+  // ---------------- epoch close: spectrum -> LDS (natural order, padded) ----------------
+  if constexpr (!MAG) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __fdiv_rn(acc[i], Kf);
+  }
+  float *spec = reinterpret_cast<float *>(gbuf);          // N + N/16 floats
+  float *feat = spec + spec_phys(N);                      // CRN_MAX_BANDS floats
+  if constexpr (G::XWAVE) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#pragma unroll
+  for (int j = 0; j < J; j++)
+#pragma unroll
+    for (int d = 0; d < R3; d++) {
+      const int k = a + 16 * (m_lo * J + j) + 256 * d;
+      spec[spec_phys(k)] = acc[j * R3 + d];
+    }
+  if constexpr (G::XWAVE) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+  if (p.spectrum != nullptr && active) {
+    float *dst = p.spectrum + epoch * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) dst[t + T * r] = spec[spec_phys(t + T * r)];
+  }
+
+  // ---------------- band sums (reference .cpp:173-191), one team of lanes per band ----------------
+  {
+    constexpr int TEAM = G::TEAM;
+    constexpr int TEAMS = T / TEAM;
+    const int team = t / TEAM, lane = t % TEAM;
+    for (int b = team; b < p.n_bands; b += TEAMS) {
+      float s = 0.f;
+      const int s0 = p.band_seg_begin[b], s1 = p.band_seg_begin[b + 1];
+      for (int sg = s0; sg < s1; sg++) {
+        const int lo = p.seg_lo[sg], hi = p.seg_hi[sg];
+        for (int k = lo + lane; k < hi; k += TEAM) s += spec[spec_phys(k)];
+      }
+#pragma unroll
+      for (int off = TEAM / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, TEAM);
+      if (lane == 0) feat[b] = MAG ? s * s : s;  // .cpp:194-197
+    }
+  }
+  if constexpr (G::XWAVE) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+  if (!active) return;
+
+  if (p.features != nullptr)
+    for (int b = t; b < p.n_bands; b += T) p.features[epoch * p.n_bands + b] = feat[b];
+
+  // ---------------- decision ----------------
+  if (p.decide == CRN_DECIDE_ANN_K) {
+    if (t == 0) {
+      // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
+      const double fb[5] = {0.0, (double)feat[0], (double)feat[1], (double)feat[2], (double)feat[3]};
+      double hid[6];
+#pragma unroll
+      for (int j = 1; j <= 5; j++) {  // .cpp:214-220
+        double s = p.ann_w_ih[0 * 6 + j];
+#pragma unroll
+        for (int i = 1; i <= 4; i++) s += fb[i] * p.ann_w_ih[i * 6 + j];
+        hid[j] = 1.0 / (1.0 + exp(-s));
+      }
+      double o[4];
+#pragma unroll
+      for (int k = 1; k <= 3; k++) {  // .cpp:229-235
+        double s = p.ann_w_ho[0 * 4 + k];
+#pragma unroll
+        for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
+        o[k] = 1.0 / (1.0 + exp(-s));
+      }
+      // .cpp:245-261 cascade
+      int d = 0;
+      if (o[1] >= p.ann_threshold) d = 1;
+      else if (o[2] >= p.ann_threshold) d = 2;
+      else if (o[3] >= p.ann_threshold) d = 3;
+      if (p.ann_out != nullptr) {
+        p.ann_out[epoch * 3 + 0] = o[1];
+        p.ann_out[epoch * 3 + 1] = o[2];
+        p.ann_out[epoch * 3 + 2] = o[3];
+      }
+      if (p.decision != nullptr) p.decision[epoch] = d;
+      if (p.occupancy != nullptr)
+        for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
+    }
+  } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
+    const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
+    if (p.occupancy != nullptr)
+      for (int b = t; b < p.n_bands; b += T)
+        p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > p.thresh[b] * ref);
+    if (t == 0 && p.decision != nullptr) {
+      int cnt = 0;
+      for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > p.thresh[b] * ref) ? 1 : 0;
+      p.decision[epoch] = cnt;
+    }
+  } else {
+    if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
+    if (p.occupancy != nullptr)
+      for (int b = t; b < p.n_bands; b += T) p.occupancy[epoch * p.n_bands + b] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch dispatch
+// ---------------------------------------------------------------------------------------------
+template <int R3, int NBUF, bool PREFETCH, bool NT, int OCC>
+static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
+  using G = Geo<R3>;
+  const unsigned grid = (unsigned)((p.n_epochs + G::GROUPS - 1) / G::GROUPS);
+  const size_t lds = (size_t)G::GROUPS * NBUF * G::GROUP_CPLX * sizeof(float2);
+  if (grid == 0) return hipSuccess;
+#define CRN_LAUNCH(MAGV, WINV)                                                                  \
+  do {                                                                                          \
+    auto kfn = sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, OCC>;                                \
+    if (lds > 48 * 1024) {                                                                      \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                            \
+    }                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);                             \
+  } while (0)
+  if (mag && win) CRN_LAUNCH(true, true);
+  else if (mag) CRN_LAUNCH(true, false);
+  else if (win) CRN_LAUNCH(false, true);
+  else CRN_LAUNCH(false, false);
+#undef CRN_LAUNCH
+  return hipGetLastError();
+}
+
+// Kernel variants selectable through crn_sense_set_variant (A/B measurements; 0 = default).
+//   id  NBUF PREFETCH NT  blocks/CU the register budget allows
+//   1    1     no     no  4
+//   2    2     no     no  2
+//   3    1     yes    no  3
+//   4    2     yes    no  2
+//   5-8  as 1-4 with nontemporal IQ loads
+// The A/B set is compiled for N = 4096 only (unless CRN_ALL_VARIANTS); other sizes use the default.
+static constexpr int kDefaultVariant = 3;
+
+template <int R3>
+static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
+  if (variant <= 0) variant = kDefaultVariant;
+#if !defined(CRN_ALL_VARIANTS)
+  if (R3 != 16) variant = kDefaultVariant;
+#endif
+  switch (variant) {
+    case 3: return launch_rn<R3, 1, true, false, 3>(p, mag, win, stream);
+#if defined(CRN_ALL_VARIANTS)
+    default:
+#else
+    default: if constexpr (R3 != 16) return hipErrorInvalidValue; else switch (variant) {
+#endif
+    case 1: return launch_rn<R3, 1, false, false, 4>(p, mag, win, stream);
+    case 2: return launch_rn<R3, 2, false, false, 2>(p, mag, win, stream);
+    case 4: return launch_rn<R3, 2, true, false, 2>(p, mag, win, stream);
+    case 5: return launch_rn<R3, 1, false, true, 4>(p, mag, win, stream);
+    case 6: return launch_rn<R3, 2, false, true, 2>(p, mag, win, stream);
+    case 7: return launch_rn<R3, 1, true, true, 3>(p, mag, win, stream);
+    case 8: return launch_rn<R3, 2, true, true, 2>(p, mag, win, stream);
+#if !defined(CRN_ALL_VARIANTS)
+    }
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
+                        hipStream_t stream) {
+  switch (fft_len) {
+    case 512: return launch_r<2>(p, mag, win, variant, stream);
+    case 1024: return launch_r<4>(p, mag, win, variant, stream);
+    case 2048: return launch_r<8>(p, mag, win, variant, stream);
+    case 4096: return launch_r<16>(p, mag, win, variant, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt) {
+  if (variant <= 0 || fft_len != 4096) variant = kDefaultVariant;
+  const int v = (variant - 1) & 3;
+  *nbuf = (v & 1) ? 2 : 1;
+  *prefetch = (v >> 1) & 1;
+  *nt = variant > 4;
+}
+
+void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block) {
+  const int r3 = fft_len / 256;
+  const int t = 16 * r3;
+  const int groups = 256 / t;
+  int nbuf, pf, nt;
+  sense_variant(fft_len, variant, &nbuf, &pf, &nt);
+  *threads = 256;
+  *epochs_per_block = groups;
+  *lds_bytes = groups * nbuf * 16 * (t + r3) * 8;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic IQ generator (measurement / test aid; see crn_synth_fill_device in crn_sense.h).
+// Mirrors the traffic shape of cognitive_engines/CE_Random_Behaviour_PU (a PU hopping uniformly
+// over the channels, CE_Random_Behaviour_PU.cpp:41-53) as seeded on-grid tones over AWGN.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
+  const long long total = p.n_epochs * p.samples_per_epoch;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long e = i / p.samples_per_epoch;
+    const long long n = i - e * p.samples_per_epoch;
+    const uint64_t h = mix64(p.seed ^ mix64((uint64_t)i));
+    const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(uint32_t)((h >> 16) & 0xFFFFFF)) * (1.0f / 16777216.0f);
+    const float r = p.noise_sigma * sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    float re = r * cs, im = r * sn;
+
+    const uint64_t he = mix64(p.seed * 0x9E3779B97F4A7C15ull + (uint64_t)e + 0x51ED27ull);
+    const int pick = (int)(he % (uint64_t)(p.n_active + 1));  // 0 = idle epoch
+    if (pick > 0) {
+      const int band = p.active_band0 + pick - 1;
+      const int nb = p.band_bins_begin[band + 1] - p.band_bins_begin[band];
+      const int *bins = p.band_bins + p.band_bins_begin[band];
+      const int nt = p.tones < nb ? p.tones : nb;
+      const int nmod = (int)(n % p.fft_len);
+      for (int j = 0; j < nt; j++) {
+        const int k = bins[(int)(((long long)(2 * j + 1) * nb) / (2 * nt))];
+        const uint64_t hp = mix64(he + 0x1234567ull * (uint64_t)(j + 1));
+        const float phase2 = (float)(uint32_t)(hp >> 40) * (2.0f / 16777216.0f);  // in units of pi
+        const int kn = (int)(((long long)k * nmod) % p.fft_len);
+        float s, c;
+        sincospif(2.0f * (float)kn / (float)p.fft_len + phase2, &s, &c);
+        re = fmaf(p.tone_amp, c, re);
+        im = fmaf(p.tone_amp, s, im);
+      }
+    }
+    p.iq[i] = make_float2(re, im);
+    if (n == 0 && p.truth != nullptr) p.truth[e] = pick;
+  }
+}
+
+hipError_t launch_synth(const SynthParams &p, hipStream_t stream) {
+  const long long total = p.n_epochs * p.samples_per_epoch;
+  if (total <= 0) return hipSuccess;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace crn

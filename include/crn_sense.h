@@ -1,0 +1,213 @@
+/*
+ * crn_sense.h — C ABI of libcrnsense: the MI355X (gfx950) spectrum-sensing hot path.
+ *
+ * This is the drop-in boundary for the FFT + energy-detect + decision loop that the
+ * reference engine runs on every USRP rx buffer
+ *   (reference: cognitive_engines/CE_Predictive_Node/CE_Predictive_Node.cpp:146-289).
+ * The reference has no FFI of its own: the path is C++ calling liquid-dsp's C API
+ *   fft_create_plan / fft_execute        (CE_Predictive_Node.cpp:42-45, :150)
+ * followed by inline loops.  Every entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are raw host or device addresses.
+ *   - every function returns 0 on success or a negative crn_status; crn_last_error()
+ *     returns a thread-local human readable message (the reference itself has no error
+ *     convention: void returns, printf + exit — src/crts.cpp:111-115).
+ *   - IQ samples are interleaved complex fp32 (re, im), 8 bytes per sample — the layout of
+ *     ExtensibleCognitiveRadio::ce_usrp_rx_buffer (include/extensible_cognitive_radio.hpp:547)
+ *     and of liquid_float_complex.
+ *   - a "frame" is one FFT input (N samples, of which the first L <= N come from the
+ *     caller and the rest are zero: CE_Predictive_Node.cpp:37,149);
+ *     an "epoch" is K consecutive frames that yield one decision (fft_averaging, .hpp:32).
+ *   - thread-compatible: one handle per host thread; not internally locked.
+ */
+#ifndef CRN_SENSE_H
+#define CRN_SENSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRN_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define CRN_API __attribute__((visibility("default")))
+#else
+#define CRN_API
+#endif
+
+#define CRN_MAX_BANDS 80   /* features per epoch (reference: 4 = NF, CH1, CH2, CH3)     */
+#define CRN_MAX_SEGS 160   /* contiguous bin ranges (reference: 5, CH1 wraps around DC) */
+#define CRN_ANN_IN 4       /* INPUTS          CE_Predictive_Node.hpp:20 */
+#define CRN_ANN_HID 5      /* HIDDEN_NEURONS  CE_Predictive_Node.hpp:21 */
+#define CRN_ANN_OUT 3      /* OUTPUT_NEURONS  CE_Predictive_Node.hpp:22 */
+
+typedef enum crn_status {
+  CRN_OK = 0,
+  CRN_ERR_ARG = -1,      /* bad argument / unsupported configuration   */
+  CRN_ERR_DEVICE = -2,   /* HIP runtime error (message has the detail) */
+  CRN_ERR_NOMEM = -3,
+  CRN_ERR_STATE = -4     /* call sequence error                        */
+} crn_status;
+
+/* How per-bin values are accumulated over the K frames of an epoch and turned into features. */
+typedef enum crn_mode {
+  /* Reference-exact: a[k] += |X[k]| / K per frame (CE_Predictive_Node.cpp:152-154);
+   * M_b = sum_{k in band b} a[k] (:173-191); feature_b = M_b * M_b (:194-197). */
+  CRN_MODE_REF_MAG = 0,
+  /* Energy detector (BASELINE.json configs[1..4]): P[k] = (sum_f |X_f[k]|^2) / K;
+   * feature_b = sum_{k in band b} P[k]. */
+  CRN_MODE_ENERGY = 1
+} crn_mode;
+
+/* How features become the occupied/idle decision. */
+typedef enum crn_decide {
+  /* 4-5-3 sigmoid net in double + first-output->=0.8 cascade (CE_Predictive_Node.cpp:214-261).
+   * Requires n_bands == 4 with band order {NF, CH1, CH2, CH3} (.cpp:200). */
+  CRN_DECIDE_ANN = 0,
+  /* occupancy[b] = feature_b > thresh[b] * (ref_band >= 0 ? feature_ref : 1), fp32. */
+  CRN_DECIDE_THRESHOLD = 1,
+  CRN_DECIDE_NONE = 2
+} crn_decide;
+
+typedef enum crn_window {
+  CRN_WINDOW_RECT = 0,   /* the reference applies no window (CE_Predictive_Node.cpp:149-150) */
+  CRN_WINDOW_HANN = 1    /* periodic Hann, w[n] = 0.5 - 0.5 cos(2 pi n / N) (Welch mode)     */
+} crn_window;
+
+/* Bins [lo, hi) of the N-point spectrum contribute to feature `band`. */
+typedef struct crn_band_seg {
+  int32_t lo;
+  int32_t hi;
+  int32_t band;
+} crn_band_seg;
+
+/* Everything the reference hard-codes as `static constexpr` members
+ * (CE_Predictive_Node.hpp:30-33,42-43,55-57) or literals (.cpp:78-120,173-191,245-261). */
+typedef struct crn_cfg {
+  int32_t abi_version;        /* must be CRN_ABI_VERSION                                   */
+  int32_t fft_len;            /* N in {512, 1024, 2048, 4096}; reference: 512 (.hpp:31)    */
+  int32_t frames_per_epoch;   /* K >= 1; reference: 10 (.hpp:32)                           */
+  int32_t hop;                /* samples between frame starts. hop == fft_len: disjoint
+                                 frames (reference). hop == fft_len/2: Welch, 50 % overlap */
+  int32_t mode;               /* crn_mode                                                  */
+  int32_t decide;             /* crn_decide                                                */
+  int32_t window;             /* crn_window                                                */
+  int32_t n_bands;            /* 1..CRN_MAX_BANDS                                          */
+  int32_t n_segs;             /* 1..CRN_MAX_SEGS                                           */
+  int32_t ref_band;           /* THRESHOLD: band whose feature scales the thresholds, or -1 */
+  int32_t device;             /* HIP device ordinal                                        */
+  int32_t reserved0;
+  crn_band_seg segs[CRN_MAX_SEGS];
+  float thresh[CRN_MAX_BANDS];
+  /* ANN weights, reference indexing: w_ih[i][j], i = 0 bias, 1..4 inputs {NF,CH1,CH2,CH3},
+   * j = 1..5 hidden (column 0 unused); w_ho[j][k], j = 0 bias, 1..5 hidden, k = 1..3 outputs
+   * (CE_Predictive_Node.hpp:66,71; values .cpp:78-120). */
+  double ann_w_ih[CRN_ANN_IN + 1][CRN_ANN_HID + 1];
+  double ann_w_ho[CRN_ANN_HID + 1][CRN_ANN_OUT + 1];
+  double ann_threshold;       /* 0.8 (.cpp:245,250,255)                                    */
+  /* Transmit frequency the engine tunes to for decision d = 0 (none), 1, 2, 3
+   * (.cpp:247,252,257: CH1 busy -> CHANNEL2, CH2 busy -> CHANNEL1, CH3 busy -> CHANNEL2;
+   * entry 0 is unused: "ALL BUSY" makes no call, .cpp:260-261). */
+  double tx_freq_for_decision[4];
+} crn_cfg;
+
+typedef struct crn_handle crn_handle;
+
+/* Per-epoch results.  Any pointer may be NULL (that output is skipped).  For the *_device
+ * entry point these are device addresses, for the *_host entry point host addresses. */
+typedef struct crn_out {
+  float *features;      /* [n_epochs][n_bands] fp32. REF_MAG order {NF,CH1,CH2,CH3}: the
+                           Features_Buffer[1..4] of CE_Predictive_Node.cpp:200               */
+  double *ann_out;      /* [n_epochs][3] Output[1..3] (.cpp:229-235); DECIDE_ANN only        */
+  int32_t *decision;    /* [n_epochs] DECIDE_ANN: 0 = "ALL BUSY" (no output >= 0.8), 1/2/3 =
+                           Channel_State[d] OCCUPIED (.cpp:245-261). DECIDE_THRESHOLD: number
+                           of occupied bands.                                               */
+  uint8_t *occupancy;   /* [n_epochs][n_bands] 1 = occupied. DECIDE_ANN: one-hot over
+                           bands 1..3 from `decision`; band 0 (NF) always 0.                */
+  float *spectrum;      /* [n_epochs][fft_len] the K-frame average per bin: fft_avg[] of
+                           CE_Predictive_Node.hpp:51 (REF_MAG) or P[k] (ENERGY).             */
+} crn_out;
+
+/* -- configuration helpers ------------------------------------------------------------ */
+
+/* The reference engine's own parameters: N=512, K=10, rectangular, REF_MAG, the five bin
+ * ranges of CE_Predictive_Node.cpp:173-191 (bin 511 is NOT part of CH1), DECIDE_ANN with the
+ * weights of .cpp:78-120, threshold 0.8, tx map 835e6/833e6/835e6 (.hpp:55-57, .cpp:245-258). */
+CRN_API int crn_cfg_reference(crn_cfg *cfg);
+
+/* Build-side generalisation used by BASELINE.json configs[1] and the headline metric:
+ * fft_len N (multiple of 512), K=10, rectangular, ENERGY, the reference's bin ranges scaled by
+ * N/512 (same frequency spans at fs = 13 MHz), DECIDE_THRESHOLD relative to the noise-floor band
+ * with thresh[b] = lambda * bins_b / bins_NF. */
+CRN_API int crn_cfg_energy_scaled(crn_cfg *cfg, int32_t fft_len, float lambda);
+
+/* Welch PSD configuration of BASELINE.json configs[2]: N-point Hann, hop N/2, n_bands equal
+ * contiguous bands covering all N bins, absolute thresholds (ref_band = -1) to be filled in by
+ * the caller in cfg->thresh. */
+CRN_API int crn_cfg_welch(crn_cfg *cfg, int32_t fft_len, int32_t frames_per_epoch, int32_t n_bands);
+
+/* -- lifecycle --------------------------------------------------------------------------- */
+
+/* Replaces the constructor's buffer zeroing + fft_create_plan (CE_Predictive_Node.cpp:36-45):
+ * validates cfg, selects cfg->device, builds twiddle/window/band tables in HBM. */
+CRN_API int crn_sense_create(const crn_cfg *cfg, crn_handle **out);
+
+/* The reference never destroys its plan (empty destructor, CE_Predictive_Node.cpp:49; no
+ * `delete CE` in the ECR); a GPU-backed engine needs an explicit release. */
+CRN_API int crn_sense_destroy(crn_handle *h);
+
+/* -- the hot path --------------------------------------------------------------------------
+ * Replaces, for n_epochs * K frames in one launch, CE_Predictive_Node.cpp:148-261:
+ *   memcpy into the zero-padded FFT buffer (:149), fft_execute (:150), magnitude + /K running
+ *   mean (:152-154), band sums + squares (:173-197), feature widening (:200), ANN (:214-235),
+ *   decision cascade (:245-261) and the fft_avg reset (:287-288).
+ *
+ * d_iq: device pointer, interleaved complex fp32.  Epoch e starts at sample
+ *       e * epoch_stride; its frame f covers samples [f*hop, f*hop + samples_per_frame) of the
+ *       epoch, zero-padded to fft_len.  samples_per_frame (L) must be in 1..fft_len — the
+ *       reference does not check (:149) and overruns its buffer when L > 512; this ABI rejects
+ *       it.  With hop < fft_len, samples_per_frame must equal fft_len.
+ *       epoch_stride <= 0 selects the dense default K * samples_per_frame (hop == fft_len)
+ *       or K * hop (overlapped: consecutive epochs share fft_len - hop samples, so the
+ *       buffer must hold n_epochs * K * hop + (fft_len - hop) samples).
+ * stream: a hipStream_t (NULL = default stream).  The call only enqueues work.
+ */
+CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs,
+                         int32_t samples_per_frame, int64_t epoch_stride,
+                         const crn_out *d_out, void *stream);
+
+/* Host-buffer convenience used by the engine wrapper: H2D, run, D2H, synchronise. */
+CRN_API int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs,
+                       int32_t samples_per_frame, int64_t epoch_stride, const crn_out *out);
+
+/* -- measurement / test aids ------------------------------------------------------------- */
+
+/* Fill d_iq with n_epochs * samples_per_epoch seeded synthetic samples on the device:
+ * complex AWGN with E|x|^2 = noise_power, plus — for the band the per-epoch occupancy pattern
+ * selects (a seeded uniform pick among {none, band 1, .., band n_active}, mirroring the PU of
+ * cognitive_engines/CE_Random_Behaviour_PU/CE_Random_Behaviour_PU.cpp:41-53) — tones_per_band
+ * on-grid tones of total RMS amplitude signal_rms.  d_truth (nullable) receives the picked band
+ * per epoch (0 = none).  The FFT grid is the handle's fft_len; "active" bands are the handle's
+ * bands 1..min(3, n_bands-1) (for Welch cfgs: all bands, pick in 0..n_bands). */
+CRN_API int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs,
+                          int64_t samples_per_epoch, uint64_t seed, float noise_power,
+                          float signal_rms, int32_t tones_per_band, int32_t *d_truth,
+                          void *stream);
+
+/* Name, registers and LDS of the sensing kernel selected for this handle. */
+CRN_API int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *threads_per_block,
+                          int32_t *lds_bytes, int32_t *epochs_per_block);
+
+/* Kernel variant override for A/B measurements (0 = default). Must be set before run. */
+CRN_API int crn_sense_set_variant(crn_handle *h, int32_t variant);
+
+CRN_API const char *crn_last_error(void);
+CRN_API int crn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRN_SENSE_H */
