@@ -185,7 +185,7 @@ int crn_sense_destroy(crn_handle *h) {
 
 int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
-  if (variant < 0 || variant > 8) return crn::fail(CRN_ERR_ARG, "variant must be 0..8");
+  if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
   h->variant = variant;
   return CRN_OK;
 }
@@ -199,10 +199,10 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
   if (lds_bytes) *lds_bytes = lds;
   if (epochs_per_block) *epochs_per_block = epb;
   if (name && name_len > 0) {
-    int nbuf = 1, pf = 0, nt = 0;
-    crn::sense_variant(h->cfg.fft_len, h->variant, &nbuf, &pf, &nt);
-    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,MAG=%d,WIN=%d>",
-                  h->cfg.fft_len / 256, nbuf, pf, nt,
+    int nbuf = 1, pf = 0, nt = 0, tl = 0;
+    crn::sense_variant(h->cfg.fft_len, h->variant, &nbuf, &pf, &nt, &tl);
+    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,MAG=%d,WIN=%d>",
+                  h->cfg.fft_len / 256, nbuf, pf, nt, tl,
                   h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT);
   }
   return CRN_OK;
@@ -229,12 +229,17 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) != 0) return crn::fail(CRN_ERR_ARG, "IQ pointer must be 8-byte aligned");
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
-  if (n_epochs > (int64_t)0x7fffffff * 1) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
+  if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
+  // a workgroup addresses its window with 32-bit byte offsets
+  if ((8 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * 8 >= ((int64_t)1 << 31))
+    return crn::fail(CRN_ERR_ARG, "epoch_stride too large (a workgroup window must stay below 2 GiB)");
   const crn_cfg &c = h->cfg;
   crn::SenseParams p{};
   p.iq = reinterpret_cast<const float2 *>(d_iq);
   p.n_epochs = n_epochs;
   p.epoch_stride = epoch_stride;
+  p.total_samples = (n_epochs - 1) * epoch_stride + (int64_t)(c.frames_per_epoch - 1) * frame_stride +
+                    (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
   p.frame_stride = frame_stride;
   p.L = samples_per_frame;
   p.K = c.frames_per_epoch;

@@ -14,6 +14,7 @@ struct SenseParams {
   const float2 *iq;        // device, interleaved complex fp32
   long long n_epochs;
   long long epoch_stride;  // samples between epoch starts
+  long long total_samples; // samples the batch holds (loads beyond it return zero)
   int frame_stride;        // samples between frame starts inside an epoch
   int L;                   // samples taken per frame (zero-padded to N)
   int K;                   // frames per epoch
@@ -57,7 +58,8 @@ struct SynthParams {
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream);
-void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt);
+int sense_num_variants();
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 

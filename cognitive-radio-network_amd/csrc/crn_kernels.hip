@@ -126,35 +126,37 @@ struct Geo {
 
 __host__ __device__ constexpr int spec_phys(int k) { return k + (k >> 4); }  // padded float index
 
+// IQ loads go through a buffer resource: the 128-bit descriptor and the per-frame / per-row part of
+// the address live in SGPRs, each lane contributes one 32-bit byte offset, and reads past the end
+// of the batch (the ragged last workgroup) return zero instead of faulting.
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
 template <bool NT>
-__device__ __forceinline__ float2 ld_iq(const float2 *p) {
-  if constexpr (NT) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
-    return make_float2(v.x, v.y);
-  } else {
-    return *p;
-  }
+__device__ __forceinline__ float2 ld_iq(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, NT ? 2 : 0);
+  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
+// u[r] = x[t + T r] of the frame that starts `frame_soff` bytes into the workgroup's window.
+// Branch-free on purpose: a data-dependent branch between issue and use makes the compiler drain
+// vmcnt at the join, which would serialise the prefetch with the compute it is meant to hide.
 template <int R3, bool NT>
-__device__ __forceinline__ void load_frame(float2 (&u)[16], const float2 *fp, int t, int L, bool active) {
-  constexpr int T = Geo<R3>::T, N = Geo<R3>::N;
-  if (!active) {
+__device__ __forceinline__ void load_frame(float2 (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                           unsigned frame_soff) {
+  constexpr int T = Geo<R3>::T;
 #pragma unroll
-    for (int r = 0; r < 16; r++) u[r] = make_float2(0.f, 0.f);
-    return;
-  }
-  if (L == N) {
+  for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, frame_soff + (unsigned)(T * r * 8));
+}
+
+// Zero padding of a short frame (L < N), applied when the registers are consumed
+// (reference: the FFT input buffer is zeroed once and only its first L entries are rewritten,
+// CE_Predictive_Node.cpp:37,149).
+template <int R3>
+__device__ __forceinline__ void mask_frame(float2 (&u)[16], int t, int L) {
+  constexpr int T = Geo<R3>::T;
 #pragma unroll
-    for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(fp + t + T * r);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int idx = t + T * r;
-      u[r] = idx < L ? ld_iq<NT>(fp + idx) : make_float2(0.f, 0.f);
-    }
-  }
+  for (int r = 0; r < 16; r++)
+    if (t + T * r >= L) u[r] = make_float2(0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -165,8 +167,12 @@ __device__ __forceinline__ void load_frame(float2 (&u)[16], const float2 *fp, in
 //   NT       nontemporal loads for the IQ stream
 //   MAG      true: CRN_MODE_REF_MAG (|X|/K accumulate, feature = M^2); false: CRN_MODE_ENERGY
 //   WIN      multiply by the window table
+//   TW2LDS   pass-2 twiddles read from an LDS table instead of 30 registers
+//   OCC      workgroups per CU the register allocation must allow
+//   ABL      measurement ablations: 0 none; 1 stream only (no FFT); 2 compute only (no re-load)
+//   FULL     every frame brings all N samples (L == N): no zero-padding mask
 // ---------------------------------------------------------------------------------------------
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool MAG, bool WIN, int OCC>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool MAG, bool WIN, bool TW2LDS, int OCC, int ABL, bool FULL>
 __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
   using G = Geo<R3>;
   constexpr int T = G::T, N = G::N, ROW = G::ROW, J = G::J;
@@ -181,13 +187,18 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
   const bool active = epoch < p.n_epochs;
 
   float2 *gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  const float2 *tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
 
   // frame-invariant twiddles, kept in registers across the K frames
   float2 tw1[16], tw2[16];
 #pragma unroll
-  for (int i = 1; i < 16; i++) {
-    tw1[i] = p.tw1[i * T + t];        // W_N^{t i}
-    tw2[i] = p.tw2[i * R3 + m_lo];    // W_T^{m_lo i}
+  for (int i = 1; i < 16; i++) tw1[i] = p.tw1[i * T + t];  // W_N^{t i}
+  if constexpr (TW2LDS) {
+    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = p.tw2[tid];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 1; i < 16; i++) tw2[i] = p.tw2[i * R3 + m_lo];  // W_T^{m_lo i}
   }
   float win[16];
   if constexpr (WIN) {
@@ -199,17 +210,43 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
 
-  const float2 *ep = p.iq + (active ? epoch * p.epoch_stride : 0);
+  // window of this workgroup: epochs [blockIdx.x * GROUPS, +GROUPS), clipped at the batch end
+  const long long first = (long long)blockIdx.x * G::GROUPS * p.epoch_stride;
+  // bytes this workgroup may touch (< 2 GiB, checked by the host): anything past it reads as zero
+  long long left = (p.total_samples - first) * 8;
+  const long long window = ((long long)G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + N) * 8;
+  if (left > window) left = window;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
+  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
+  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * 8u;
+  const unsigned fbytes = (unsigned)p.frame_stride * 8u;
   const int K = p.K;
   const float Kf = (float)K;
 
   float2 u[16], nx[16];
-  load_frame<R3, NT>(u, ep, t, p.L, active);
+  load_frame<R3, NT>(u, rsrc, voff, 0u);
+  [[maybe_unused]] float2 u0[16];
+  if constexpr (ABL == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) u0[r] = u[r];
+  }
 
   for (int f = 0; f < K; f++) {
-    if constexpr (PREFETCH) {
-      if (f + 1 < K) load_frame<R3, NT>(nx, ep + (long long)(f + 1) * p.frame_stride, t, p.L, active);
+    if constexpr (PREFETCH && ABL != 2) {
+      // always 16 loads, so the compiler can wait with a counted vmcnt instead of draining at a
+      // join; after the last frame they point outside the window and fetch nothing
+      load_frame<R3, NT>(nx, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
     }
+    if constexpr (!FULL) mask_frame<R3>(u, t, p.L);
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) u[r] = make_float2(u0[r].x + (float)f * 1e-30f, u0[r].y);
+    }
+    if constexpr (ABL == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[i] += u[i].x + u[i].y;
+    } else {
     float2 *buf = gbuf + (NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
 
     if constexpr (WIN) {
@@ -240,7 +277,7 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
     // ---- pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c} ----
     dft16(u, v);
 #pragma unroll
-    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], tw2[i]);
+    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], TW2LDS ? tw2_lds[i * R3 + m_lo] : tw2[i]);
 
     // ---- exchange 2 (inside the R3 lanes sharing `a`): slot (c, m) at c*R3 + m + c/J ----
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -294,12 +331,15 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
         acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, acc[i]));
       }
     }
+    }  // ABL != 1
 
-    if constexpr (PREFETCH) {
+    if constexpr (ABL == 2) {
+      // keep the input registers
+    } else if constexpr (PREFETCH) {
 #pragma unroll
       for (int r = 0; r < 16; r++) u[r] = nx[r];
     } else {
-      if (f + 1 < K) load_frame<R3, NT>(u, ep + (long long)(f + 1) * p.frame_stride, t, p.L, active);
+      load_frame<R3, NT>(u, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
     }
   }
 
@@ -408,15 +448,17 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
 // ---------------------------------------------------------------------------------------------
 // launch dispatch
 // ---------------------------------------------------------------------------------------------
-template <int R3, int NBUF, bool PREFETCH, bool NT, int OCC>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL = 0>
 static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   using G = Geo<R3>;
   const unsigned grid = (unsigned)((p.n_epochs + G::GROUPS - 1) / G::GROUPS);
-  const size_t lds = (size_t)G::GROUPS * NBUF * G::GROUP_CPLX * sizeof(float2);
+  const size_t lds = ((size_t)G::GROUPS * NBUF * G::GROUP_CPLX + (TW2LDS ? 16 * R3 : 0)) * sizeof(float2);
   if (grid == 0) return hipSuccess;
+  const bool full = p.L == G::N;
 #define CRN_LAUNCH(MAGV, WINV)                                                                  \
   do {                                                                                          \
-    auto kfn = sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, OCC>;                                \
+    auto kfn = full ? sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, true>  \
+                    : sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, false>; \
     if (lds > 48 * 1024) {                                                                      \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -433,38 +475,48 @@ static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_
 }
 
 // Kernel variants selectable through crn_sense_set_variant (A/B measurements; 0 = default).
-//   id  NBUF PREFETCH NT  blocks/CU the register budget allows
-//   1    1     no     no  4
-//   2    2     no     no  2
-//   3    1     yes    no  3
-//   4    2     yes    no  2
-//   5-8  as 1-4 with nontemporal IQ loads
-// The A/B set is compiled for N = 4096 only (unless CRN_ALL_VARIANTS); other sizes use the default.
-static constexpr int kDefaultVariant = 3;
+struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl; };
+static constexpr VariantDesc kVariants[] = {
+    /* 0 (unused) */ {0, 0, 0, 0, 0, 0},
+    /* 1 */ {1, 0, 0, 1, 4, 0},
+    /* 2 */ {2, 0, 0, 0, 2, 0},
+    /* 3 */ {1, 1, 0, 1, 3, 0},
+    /* 4 */ {2, 1, 0, 0, 2, 0},
+    /* 5 */ {1, 0, 1, 1, 4, 0},
+    /* 6 */ {2, 0, 1, 0, 2, 0},
+    /* 7 */ {1, 1, 1, 1, 3, 0},
+    /* 8 */ {2, 1, 1, 0, 2, 0},
+    /* 9 */ {2, 1, 1, 1, 2, 0},
+    /* 10 */ {1, 1, 1, 0, 2, 0},
+    /* 11 */ {2, 1, 1, 0, 2, 1},  // ablation: stream only
+    /* 12 */ {2, 1, 1, 0, 2, 2},  // ablation: compute only
+    /* 13 */ {1, 1, 1, 1, 4, 0},
+};
+static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
+static constexpr int kDefaultVariant = 8;
 
+// The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
-  if (variant <= 0) variant = kDefaultVariant;
-#if !defined(CRN_ALL_VARIANTS)
-  if (R3 != 16) variant = kDefaultVariant;
-#endif
-  switch (variant) {
-    case 3: return launch_rn<R3, 1, true, false, 3>(p, mag, win, stream);
-#if defined(CRN_ALL_VARIANTS)
-    default:
-#else
-    default: if constexpr (R3 != 16) return hipErrorInvalidValue; else switch (variant) {
-#endif
-    case 1: return launch_rn<R3, 1, false, false, 4>(p, mag, win, stream);
-    case 2: return launch_rn<R3, 2, false, false, 2>(p, mag, win, stream);
-    case 4: return launch_rn<R3, 2, true, false, 2>(p, mag, win, stream);
-    case 5: return launch_rn<R3, 1, false, true, 4>(p, mag, win, stream);
-    case 6: return launch_rn<R3, 2, false, true, 2>(p, mag, win, stream);
-    case 7: return launch_rn<R3, 1, true, true, 3>(p, mag, win, stream);
-    case 8: return launch_rn<R3, 2, true, true, 2>(p, mag, win, stream);
-#if !defined(CRN_ALL_VARIANTS)
+  if (variant <= 0 || variant > kNumVariants || R3 != 16) variant = kDefaultVariant;
+  if constexpr (R3 != 16) {
+    return launch_rn<R3, 2, true, true, false, 2>(p, mag, win, stream);
+  } else {
+    switch (variant) {
+      case 1: return launch_rn<R3, 1, false, false, true, 4>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 2, false, false, false, 2>(p, mag, win, stream);
+      case 3: return launch_rn<R3, 1, true, false, true, 3>(p, mag, win, stream);
+      case 4: return launch_rn<R3, 2, true, false, false, 2>(p, mag, win, stream);
+      case 5: return launch_rn<R3, 1, false, true, true, 4>(p, mag, win, stream);
+      case 6: return launch_rn<R3, 2, false, true, false, 2>(p, mag, win, stream);
+      case 7: return launch_rn<R3, 1, true, true, true, 3>(p, mag, win, stream);
+      case 8: return launch_rn<R3, 2, true, true, false, 2>(p, mag, win, stream);
+      case 9: return launch_rn<R3, 2, true, true, true, 2>(p, mag, win, stream);
+      case 10: return launch_rn<R3, 1, true, true, false, 2>(p, mag, win, stream);
+      case 11: return launch_rn<R3, 2, true, true, false, 2, 1>(p, mag, win, stream);
+      case 12: return launch_rn<R3, 2, true, true, false, 2, 2>(p, mag, win, stream);
+      case 13: return launch_rn<R3, 1, true, true, true, 4>(p, mag, win, stream);
     }
-#endif
   }
   return hipErrorInvalidValue;
 }
@@ -480,23 +532,25 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
   }
 }
 
-void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt) {
-  if (variant <= 0 || fft_len != 4096) variant = kDefaultVariant;
-  const int v = (variant - 1) & 3;
-  *nbuf = (v & 1) ? 2 : 1;
-  *prefetch = (v >> 1) & 1;
-  *nt = variant > 4;
+int sense_num_variants() { return kNumVariants; }
+
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds) {
+  if (variant <= 0 || variant > kNumVariants || fft_len != 4096) variant = kDefaultVariant;
+  *nbuf = kVariants[variant].nbuf;
+  *prefetch = kVariants[variant].prefetch;
+  *nt = kVariants[variant].nt;
+  *tw2lds = kVariants[variant].tw2lds;
 }
 
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block) {
   const int r3 = fft_len / 256;
   const int t = 16 * r3;
   const int groups = 256 / t;
-  int nbuf, pf, nt;
-  sense_variant(fft_len, variant, &nbuf, &pf, &nt);
+  int nbuf, pf, nt, tl;
+  sense_variant(fft_len, variant, &nbuf, &pf, &nt, &tl);
   *threads = 256;
   *epochs_per_block = groups;
-  *lds_bytes = groups * nbuf * 16 * (t + r3) * 8;
+  *lds_bytes = (groups * nbuf * 16 * (t + r3) + (tl ? 16 * r3 : 0)) * 8;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,7 +41,8 @@ def check_against_oracle(cfg, iq, n_epochs, L=None, got=None):
         assert np.abs(got["ann_out"] - want["ann_out"]).max() < 1e-6
     elif cfg.decide == cs.DECIDE_THRESHOLD:
         ref = want["features"][:, cfg.ref_band:cfg.ref_band + 1] if cfg.ref_band >= 0 else 1.0
-        thr = np.array(cfg.thresh[:cfg.n_bands], np.float32)[None, :] * ref
+        thr = np.broadcast_to(np.array(cfg.thresh[:cfg.n_bands], np.float32)[None, :] * ref,
+                              want["features"].shape)
         fin = np.isfinite(thr)
         assert (np.abs(want["features"][fin] / thr[fin] - 1) > 1e-4).all(), "fixture inside the margin band"
     assert np.array_equal(got["decision"], want["decision"])
