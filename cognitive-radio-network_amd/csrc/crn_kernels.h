@@ -59,7 +59,7 @@ struct SynthParams {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream);
 int sense_num_variants();
-void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds);
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 

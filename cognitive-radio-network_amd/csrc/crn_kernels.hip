@@ -24,64 +24,113 @@
 
 namespace crn {
 
-// ---------------------------------------------------------------------------------------------
-// complex helpers (forward transform: W = exp(-j theta))
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-  return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
-}
+// A complex fp32 value lives in an even-aligned VGPR pair (re, im) so the packed-f32 VALU forms
+// (v_pk_add/mul/fma_f32) work on it directly.
+typedef float cx __attribute__((ext_vector_type(2)));
+#define CRN_DEV static __device__ __forceinline__
 
-// 4-point forward DFT, natural order in and out.
-__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
-  const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-  const float2 s13 = cadd(a1, a3), d13 = csub(a1, a3);
-  a0 = cadd(s02, s13);
-  a2 = csub(s02, s13);
-  a1 = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - j d13
-  a3 = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + j d13
-}
-
-__device__ __forceinline__ void dft2(float2 &a0, float2 &a1) {
-  const float2 s = cadd(a0, a1), d = csub(a0, a1);
-  a0 = s;
-  a1 = d;
-}
+// ---------------------------------------------------------------------------------------------
+// Complex arithmetic, forward transform convention W = exp(-j theta).
+//
+// PK = true: one VOP3P instruction per complex add / rotate-add and two per complex multiply,
+// with the re/im swaps and sign flips expressed through op_sel / neg modifiers, so no v_mov is
+// spent on shuffling.  A lone wave issues one VALU instruction every ~4.6 cycles on gfx950
+// whether it is packed or not (measured, tools/valu_rate.hip), so at the 2-3 waves per SIMD this
+// kernel runs at, halving the instruction count is what shortens a frame.
+// PK = false: plain scalar fp32 (reference build of the same arithmetic, used for A/B).
+// Operand semantics (VOP3P, 64-bit sources): op_sel[i] picks the half of source i feeding the
+// LOW result, op_sel_hi[i] the half feeding the HIGH result; neg_lo / neg_hi negate source i for
+// the low / high result.
+// ---------------------------------------------------------------------------------------------
+template <bool PK>
+struct M {
+  CRN_DEV cx add(cx a, cx b) {
+    if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+    else return cx{a.x + b.x, a.y + b.y};
+  }
+  CRN_DEV cx sub(cx a, cx b) {
+    if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+    else return cx{a.x - b.x, a.y - b.y};
+  }
+  // a + (-j) b = (a.x + b.y, a.y - b.x)
+  CRN_DEV cx add_mj(cx a, cx b) {
+    if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+    else return cx{a.x + b.y, a.y - b.x};
+  }
+  // a - (-j) b = (a.x - b.y, a.y + b.x)
+  CRN_DEV cx sub_mj(cx a, cx b) {
+    if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+    else return cx{a.x - b.y, a.y + b.x};
+  }
+  // a * w, w in VGPRs (per-lane twiddle)
+  CRN_DEV cx mul(cx a, cx w) {
+    if constexpr (PK) {
+      cx t, d;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));  // (a.x w.x, a.y w.x)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+          : "=v"(d) : "v"(a), "v"(w), "v"(t));                                     // (-a.y w.y + t.x, a.x w.y + t.y)
+      return d;
+    } else {
+      return cx{fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y)};
+    }
+  }
+  // a * w, w a wave-uniform constant held in an SGPR pair
+  CRN_DEV cx mul_c(cx a, cx w) {
+    if constexpr (PK) {
+      cx t, d;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+          : "=v"(d) : "v"(a), "s"(w), "v"(t));
+      return d;
+    } else {
+      return cx{fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y)};
+    }
+  }
+};
 
 #define CRN_C1 0.92387953251128674f  // cos(pi/8)
 #define CRN_S1 0.38268343236508977f  // sin(pi/8)
 #define CRN_H 0.70710678118654752f   // sqrt(1/2)
 
-__device__ __forceinline__ float2 mul_w8_1(float2 a) {  // * exp(-j pi/4) = (h, -h)
-  return make_float2(CRN_H * (a.x + a.y), CRN_H * (a.y - a.x));
+// 4-point forward DFT in place.  B2MJ: input a2 still lacks a factor -j (a folded W16^4 / W8^2).
+template <bool PK, bool B2MJ = false>
+CRN_DEV void dft4(cx &a0, cx &a1, cx &a2, cx &a3) {
+  using m = M<PK>;
+  const cx s02 = B2MJ ? m::add_mj(a0, a2) : m::add(a0, a2);
+  const cx d02 = B2MJ ? m::sub_mj(a0, a2) : m::sub(a0, a2);
+  const cx s13 = m::add(a1, a3), d13 = m::sub(a1, a3);
+  a0 = m::add(s02, s13);
+  a2 = m::sub(s02, s13);
+  a1 = m::add_mj(d02, d13);  // d02 - j d13
+  a3 = m::sub_mj(d02, d13);  // d02 + j d13
 }
-__device__ __forceinline__ float2 mul_w8_3(float2 a) {  // * exp(-j 3pi/4) = (-h, -h)
-  return make_float2(CRN_H * (a.y - a.x), -CRN_H * (a.x + a.y));
-}
-__device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }  // * (-j)
 
-// 16-point forward DFT: in[r] -> out[a], both natural order, as 4 x 4 (two radix-4 levels).
-__device__ __forceinline__ void dft16(const float2 (&in)[16], float2 (&out)[16]) {
-  float2 y[16];
+// 16-point forward DFT, natural order in and out, as 4 x 4.
+template <bool PK>
+CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16]) {
+  using m = M<PK>;
+  cx y[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) y[i] = in[i];
-  // level A: for each r0, DFT4 over r1 (index r = r0 + 4 r1); result a0 replaces r1
+  // level A: for each r0, DFT4 over r1 (r = r0 + 4 r1); a0 replaces r1
 #pragma unroll
-  for (int r0 = 0; r0 < 4; r0++) dft4(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
-  // internal twiddles W16^{r0 a0}, element (r0, a0) sits at y[r0 + 4 a0]
-  y[1 + 4 * 1] = cmul(y[1 + 4 * 1], make_float2(CRN_C1, -CRN_S1));  // W16^1
-  y[1 + 4 * 2] = mul_w8_1(y[1 + 4 * 2]);                             // W16^2
-  y[1 + 4 * 3] = cmul(y[1 + 4 * 3], make_float2(CRN_S1, -CRN_C1));  // W16^3
-  y[2 + 4 * 1] = mul_w8_1(y[2 + 4 * 1]);                             // W16^2
-  y[2 + 4 * 2] = mul_mj(y[2 + 4 * 2]);                               // W16^4
-  y[2 + 4 * 3] = mul_w8_3(y[2 + 4 * 3]);                             // W16^6
-  y[3 + 4 * 1] = cmul(y[3 + 4 * 1], make_float2(CRN_S1, -CRN_C1));  // W16^3
-  y[3 + 4 * 2] = mul_w8_3(y[3 + 4 * 2]);                             // W16^6
-  y[3 + 4 * 3] = cmul(y[3 + 4 * 3], make_float2(-CRN_C1, CRN_S1));  // W16^9
-  // level B: for each a0, DFT4 over r0; result a1 replaces r0; X[a0 + 4 a1] = y[a1 + 4 a0]
-#pragma unroll
-  for (int a0 = 0; a0 < 4; a0++) dft4(y[4 * a0], y[4 * a0 + 1], y[4 * a0 + 2], y[4 * a0 + 3]);
+  for (int r0 = 0; r0 < 4; r0++) dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+  // W16^{r0 a0} on element (r0, a0) = y[r0 + 4 a0]; W16^4 = -j is folded into level B
+  const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
+  const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
+  y[1 + 4 * 1] = m::mul_c(y[1 + 4 * 1], w1);
+  y[1 + 4 * 2] = m::mul_c(y[1 + 4 * 2], w2);
+  y[1 + 4 * 3] = m::mul_c(y[1 + 4 * 3], w3);
+  y[2 + 4 * 1] = m::mul_c(y[2 + 4 * 1], w2);
+  y[2 + 4 * 3] = m::mul_c(y[2 + 4 * 3], w6);
+  y[3 + 4 * 1] = m::mul_c(y[3 + 4 * 1], w3);
+  y[3 + 4 * 2] = m::mul_c(y[3 + 4 * 2], w6);
+  y[3 + 4 * 3] = m::mul_c(y[3 + 4 * 3], w9);
+  // level B: for each a0, DFT4 over r0; X[a0 + 4 a1] = y[a1 + 4 a0]
+  dft4<PK>(y[0], y[1], y[2], y[3]);
+  dft4<PK>(y[4], y[5], y[6], y[7]);
+  dft4<PK, true>(y[8], y[9], y[10], y[11]);  // y[10] carries the folded -j
+  dft4<PK>(y[12], y[13], y[14], y[15]);
 #pragma unroll
   for (int a0 = 0; a0 < 4; a0++)
 #pragma unroll
@@ -89,23 +138,22 @@ __device__ __forceinline__ void dft16(const float2 (&in)[16], float2 (&out)[16])
 }
 
 // 8-point forward DFT as 2 x 4.
-__device__ __forceinline__ void dft8(const float2 (&in)[8], float2 (&out)[8]) {
-  float2 y[8];
+template <bool PK>
+CRN_DEV void dft8(const cx (&in)[8], cx (&out)[8]) {
+  using m = M<PK>;
+  cx y[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) y[i] = in[i];
-  // r = r0 + 2 r1 (r0 < 2, r1 < 4): DFT4 over r1 -> a0 at y[r0 + 2 a0]
-  dft4(y[0], y[2], y[4], y[6]);
-  dft4(y[1], y[3], y[5], y[7]);
-  // twiddles W8^{r0 a0} for r0 = 1
-  y[1 + 2 * 1] = mul_w8_1(y[1 + 2 * 1]);
-  y[1 + 2 * 2] = mul_mj(y[1 + 2 * 2]);
-  y[1 + 2 * 3] = mul_w8_3(y[1 + 2 * 3]);
-  // DFT2 over r0 -> a1; X[a0 + 4 a1]
+  dft4<PK>(y[0], y[2], y[4], y[6]);  // r = r0 + 2 r1: DFT4 over r1 -> a0 at y[r0 + 2 a0]
+  dft4<PK>(y[1], y[3], y[5], y[7]);
+  const cx w1 = {CRN_H, -CRN_H}, w3 = {-CRN_H, -CRN_H};
+  y[3] = m::mul_c(y[3], w1);  // W8^1 on (r0 = 1, a0 = 1)
+  y[7] = m::mul_c(y[7], w3);  // W8^3 on (r0 = 1, a0 = 3); W8^2 = -j on y[5] folded below
 #pragma unroll
   for (int a0 = 0; a0 < 4; a0++) {
-    dft2(y[2 * a0], y[2 * a0 + 1]);
-    out[a0] = y[2 * a0];
-    out[a0 + 4] = y[2 * a0 + 1];
+    const cx e = y[2 * a0], o = y[2 * a0 + 1];
+    out[a0] = a0 == 2 ? m::add_mj(e, o) : m::add(e, o);
+    out[a0 + 4] = a0 == 2 ? m::sub_mj(e, o) : m::sub(e, o);
   }
 }
 
@@ -128,42 +176,47 @@ __host__ __device__ constexpr int spec_phys(int k) { return k + (k >> 4); }  // 
 
 // IQ loads go through a buffer resource: the 128-bit descriptor and the per-frame / per-row part of
 // the address live in SGPRs, each lane contributes one 32-bit byte offset, and reads past the end
-// of the batch (the ragged last workgroup) return zero instead of faulting.
+// of the workgroup's window (ragged last workgroup, the prefetch after the last frame) return zero
+// without touching memory.
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 template <bool NT>
-__device__ __forceinline__ float2 ld_iq(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+CRN_DEV cx ld_iq(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, NT ? 2 : 0);
-  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  return cx{__uint_as_float(v.x), __uint_as_float(v.y)};
 }
 
 // u[r] = x[t + T r] of the frame that starts `frame_soff` bytes into the workgroup's window.
-// Branch-free on purpose: a data-dependent branch between issue and use makes the compiler drain
-// vmcnt at the join, which would serialise the prefetch with the compute it is meant to hide.
+// Branch-free on purpose: a branch between issue and use makes the compiler drain vmcnt at the
+// join, which serialises the prefetch with the compute it is meant to hide.
 template <int R3, bool NT>
-__device__ __forceinline__ void load_frame(float2 (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
-                                           unsigned frame_soff) {
+CRN_DEV void load_frame(cx (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned frame_soff) {
   constexpr int T = Geo<R3>::T;
 #pragma unroll
   for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, frame_soff + (unsigned)(T * r * 8));
 }
 
-// Zero padding of a short frame (L < N), applied when the registers are consumed
-// (reference: the FFT input buffer is zeroed once and only its first L entries are rewritten,
+// Zero padding of a short frame (L < N), applied when the registers are consumed (reference: the
+// FFT input buffer is zeroed once and only its first L entries are rewritten,
 // CE_Predictive_Node.cpp:37,149).
 template <int R3>
-__device__ __forceinline__ void mask_frame(float2 (&u)[16], int t, int L) {
+CRN_DEV void mask_frame(cx (&u)[16], int t, int L) {
   constexpr int T = Geo<R3>::T;
 #pragma unroll
   for (int r = 0; r < 16; r++)
-    if (t + T * r >= L) u[r] = make_float2(0.f, 0.f);
+    if (t + T * r >= L) u[r] = cx{0.f, 0.f};
+}
+
+CRN_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------
-// the sensing kernel
+// Kernel configuration (compile time).
 //   R3       N = 256 * R3
 //   NBUF     LDS exchange buffers (2 drops the second barrier per frame when T > 64)
-//   PREFETCH issue frame f+1's HBM loads before computing frame f
+//   PREFETCH issue frame f+1's HBM loads before computing frame f (two register sets, ping-pong)
 //   NT       nontemporal loads for the IQ stream
 //   MAG      true: CRN_MODE_REF_MAG (|X|/K accumulate, feature = M^2); false: CRN_MODE_ENERGY
 //   WIN      multiply by the window table
@@ -171,12 +224,141 @@ __device__ __forceinline__ void mask_frame(float2 (&u)[16], int t, int L) {
 //   OCC      workgroups per CU the register allocation must allow
 //   ABL      measurement ablations: 0 none; 1 stream only (no FFT); 2 compute only (no re-load)
 //   FULL     every frame brings all N samples (L == N): no zero-padding mask
+//   PK       packed-f32 butterflies (see M<PK>)
 // ---------------------------------------------------------------------------------------------
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool MAG, bool WIN, bool TW2LDS, int OCC, int ABL, bool FULL>
-__global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
+template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
+          bool FULL_, bool PK_>
+struct Cfg {
+  static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
+  static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
+                        PK = PK_;
+};
+
+// Per-thread state that lives across the frames of an epoch.
+template <class C>
+struct FrameCtx {
+  cx tw1[16];   // W_N^{t i}
+  cx tw2[16];   // W_T^{m_lo i} (registers unless TW2LDS)
+  float win[16];
+  float acc[16];
+  const cx *tw2_lds;
+  cx *gbuf;     // this group's exchange buffers
+  int t, a, m_lo, L;
+  float Kf;
+};
+
+// One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` holds x[t + T r]
+// on entry and is clobbered.
+template <class C>
+CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
+  constexpr int R3 = C::R3;
   using G = Geo<R3>;
-  constexpr int T = G::T, N = G::N, ROW = G::ROW, J = G::J;
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  using m = M<C::PK>;
+  constexpr int ROW = G::ROW, J = G::J;
+  cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
+
+  if constexpr (!C::FULL) mask_frame<R3>(u, c.t, c.L);
+  if constexpr (C::WIN) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
+  }
+
+  // ---- pass 1: DFT16 over r, twiddle W_N^{t a} ----
+  cx v[16];
+  dft16<C::PK>(u, v);
+#pragma unroll
+  for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
+
+  // ---- exchange 1: [a][t] ----
+  if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();  // rows may still be read as exchange 2
+#pragma unroll
+  for (int i = 0; i < 16; i++) buf[i * ROW + c.t] = v[i];
+  if constexpr (G::XWAVE) __syncthreads();
+  else wave_sync();
+  cx *row = buf + c.a * ROW;
+#pragma unroll
+  for (int i = 0; i < 16; i++) u[i] = row[R3 * i + c.m_lo];
+
+  // ---- pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c} ----
+  dft16<C::PK>(u, v);
+#pragma unroll
+  for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], C::TW2LDS ? c.tw2_lds[i * R3 + c.m_lo] : c.tw2[i]);
+
+  // ---- exchange 2 (inside the R3 lanes sharing `a`): slot (c, m) at c*R3 + m + c/J ----
+  wave_sync();
+#pragma unroll
+  for (int cc = 0; cc < 16; cc++) row[cc * R3 + c.m_lo + cc / J] = v[cc];
+  wave_sync();
+  // thread (a, g = m_lo) takes c = g*J + j, all m
+#pragma unroll
+  for (int j = 0; j < J; j++)
+#pragma unroll
+    for (int mm = 0; mm < R3; mm++) u[j * R3 + mm] = row[(c.m_lo * J + j) * R3 + mm + c.m_lo];
+
+  // ---- pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d lands in v[j*R3 + d] ----
+  if constexpr (R3 == 16) {
+    dft16<C::PK>(u, v);
+  } else if constexpr (R3 == 8) {
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      cx in8[8], out8[8];
+#pragma unroll
+      for (int mm = 0; mm < 8; mm++) in8[mm] = u[j * 8 + mm];
+      dft8<C::PK>(in8, out8);
+#pragma unroll
+      for (int mm = 0; mm < 8; mm++) v[j * 8 + mm] = out8[mm];
+    }
+  } else if constexpr (R3 == 4) {
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      dft4<C::PK>(u[j * 4], u[j * 4 + 1], u[j * 4 + 2], u[j * 4 + 3]);
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++) v[j * 4 + mm] = u[j * 4 + mm];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      v[j * 2] = m::add(u[j * 2], u[j * 2 + 1]);
+      v[j * 2 + 1] = m::sub(u[j * 2], u[j * 2 + 1]);
+    }
+  }
+
+  // ---- per-bin accumulate over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K) ----
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if constexpr (C::MAG) {
+      const float mag = __fsqrt_rn(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+      c.acc[i] += __fdiv_rn(mag, c.Kf);
+    } else {
+      c.acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, c.acc[i]));
+    }
+  }
+}
+
+template <class C>
+CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]) {
+  if constexpr (C::ABL == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) cur[r] = cx{u0[r].x + (float)f * 1e-30f, u0[r].y};
+  }
+  if constexpr (C::ABL == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) c.acc[i] += cur[i].x + cur[i].y;
+  } else {
+    frame_compute<C>(cur, c, f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sensing kernel
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p) {
+  constexpr int R3 = C::R3, NBUF = C::NBUF;
+  constexpr bool NT = C::NT, MAG = C::MAG;
+  using G = Geo<R3>;
+  constexpr int T = G::T, N = G::N, J = G::J;
+  extern __shared__ __attribute__((aligned(16))) cx lds[];
 
   const int tid = threadIdx.x;
   const int grp = tid / T;
@@ -186,29 +368,32 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
   const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
   const bool active = epoch < p.n_epochs;
 
-  float2 *gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
-  const float2 *tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  FrameCtx<C> c;
+  c.t = t;
+  c.a = a;
+  c.m_lo = m_lo;
+  c.L = p.L;
+  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  const int K = p.K;
+  c.Kf = (float)K;
 
   // frame-invariant twiddles, kept in registers across the K frames
-  float2 tw1[16], tw2[16];
 #pragma unroll
-  for (int i = 1; i < 16; i++) tw1[i] = p.tw1[i * T + t];  // W_N^{t i}
-  if constexpr (TW2LDS) {
-    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = p.tw2[tid];
+  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  if constexpr (C::TW2LDS) {
+    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
     __syncthreads();
   } else {
 #pragma unroll
-    for (int i = 1; i < 16; i++) tw2[i] = p.tw2[i * R3 + m_lo];  // W_T^{m_lo i}
+    for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
   }
-  float win[16];
-  if constexpr (WIN) {
+  if constexpr (C::WIN) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) win[r] = p.window[t + T * r];
+    for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
   }
-
-  float acc[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
 
   // window of this workgroup: epochs [blockIdx.x * GROUPS, +GROUPS), clipped at the batch end
   const long long first = (long long)blockIdx.x * G::GROUPS * p.epoch_stride;
@@ -221,137 +406,46 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
   constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
   const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * 8u;
   const unsigned fbytes = (unsigned)p.frame_stride * 8u;
-  const int K = p.K;
-  const float Kf = (float)K;
 
-  float2 u[16], nx[16];
-  load_frame<R3, NT>(u, rsrc, voff, 0u);
-  [[maybe_unused]] float2 u0[16];
-  if constexpr (ABL == 2) {
+  cx ua[16], ub[16];
+  [[maybe_unused]] cx u0[16];
+  load_frame<R3, NT>(ua, rsrc, voff, 0u);
+  if constexpr (C::ABL == 2) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) u0[r] = u[r];
+    for (int r = 0; r < 16; r++) u0[r] = ua[r];
   }
 
-  for (int f = 0; f < K; f++) {
-    if constexpr (PREFETCH && ABL != 2) {
-      // always 16 loads, so the compiler can wait with a counted vmcnt instead of draining at a
-      // join; after the last frame they point outside the window and fetch nothing
-      load_frame<R3, NT>(nx, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
+  if constexpr (C::PREFETCH && C::ABL != 2) {
+    // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
+    // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
+    // last frame they point outside the window and fetch nothing.
+    int f = 0;
+    for (; f + 1 < K; f += 2) {
+      load_frame<R3, NT>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+      frame_step<C>(ua, c, f, u0);
+      load_frame<R3, NT>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+      frame_step<C>(ub, c, f + 1, u0);
     }
-    if constexpr (!FULL) mask_frame<R3>(u, t, p.L);
-    if constexpr (ABL == 2) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) u[r] = make_float2(u0[r].x + (float)f * 1e-30f, u0[r].y);
-    }
-    if constexpr (ABL == 1) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[i] += u[i].x + u[i].y;
-    } else {
-    float2 *buf = gbuf + (NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
-
-    if constexpr (WIN) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) u[r] = make_float2(u[r].x * win[r], u[r].y * win[r]);
-    }
-
-    // ---- pass 1: DFT16 over r, twiddle W_N^{t a} ----
-    float2 v[16];
-    dft16(u, v);
-#pragma unroll
-    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], tw1[i]);
-
-    // ---- exchange 1: [a][t] ----
-    if constexpr (G::XWAVE && NBUF == 1) __syncthreads();  // rows may still be read as exchange 2
-#pragma unroll
-    for (int i = 0; i < 16; i++) buf[i * ROW + t] = v[i];
-    if constexpr (G::XWAVE) {
-      __syncthreads();
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    float2 *row = buf + a * ROW;
-#pragma unroll
-    for (int i = 0; i < 16; i++) u[i] = row[R3 * i + m_lo];
-
-    // ---- pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c} ----
-    dft16(u, v);
-#pragma unroll
-    for (int i = 1; i < 16; i++) v[i] = cmul(v[i], TW2LDS ? tw2_lds[i * R3 + m_lo] : tw2[i]);
-
-    // ---- exchange 2 (inside the R3 lanes sharing `a`): slot (c, m) at c*R3 + m + c/J ----
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < 16; c++) row[c * R3 + m_lo + c / J] = v[c];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // thread (a, g = m_lo) takes c = g*J + j, all m
-#pragma unroll
-    for (int j = 0; j < J; j++)
-#pragma unroll
-      for (int m = 0; m < R3; m++) u[j * R3 + m] = row[(m_lo * J + j) * R3 + m + m_lo];
-
-    // ---- pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d at v[j*R3 + d] ----
-    if constexpr (R3 == 16) {
-      dft16(u, v);
-    } else if constexpr (R3 == 8) {
-#pragma unroll
-      for (int j = 0; j < J; j++) {
-        float2 in8[8], out8[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) in8[m] = u[j * 8 + m];
-        dft8(in8, out8);
-#pragma unroll
-        for (int m = 0; m < 8; m++) v[j * 8 + m] = out8[m];
-      }
-    } else if constexpr (R3 == 4) {
-#pragma unroll
-      for (int j = 0; j < J; j++) {
-        dft4(u[j * 4], u[j * 4 + 1], u[j * 4 + 2], u[j * 4 + 3]);
-#pragma unroll
-        for (int m = 0; m < 4; m++) v[j * 4 + m] = u[j * 4 + m];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < J; j++) {
-        dft2(u[j * 2], u[j * 2 + 1]);
-        v[j * 2] = u[j * 2];
-        v[j * 2 + 1] = u[j * 2 + 1];
-      }
-    }
-
-    // ---- per-bin accumulate over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K) ----
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if constexpr (MAG) {
-        const float mag = __fsqrt_rn(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
-        acc[i] += __fdiv_rn(mag, Kf);
-      } else {
-        acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, acc[i]));
-      }
-    }
-    }  // ABL != 1
-
-    if constexpr (ABL == 2) {
-      // keep the input registers
-    } else if constexpr (PREFETCH) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) u[r] = nx[r];
-    } else {
-      load_frame<R3, NT>(u, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
+    if (f < K) frame_step<C>(ua, c, f, u0);
+  } else {
+    for (int f = 0; f < K; f++) {
+      frame_step<C>(ua, c, f, u0);
+      if constexpr (C::ABL != 2)
+        load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
     }
   }
 
   // ---------------- epoch close: spectrum -> LDS (natural order, padded) ----------------
+  float (&acc)[16] = c.acc;
+  const float Kf = c.Kf;
   if constexpr (!MAG) {
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = __fdiv_rn(acc[i], Kf);
   }
-  float *spec = reinterpret_cast<float *>(gbuf);          // N + N/16 floats
+  float *spec = reinterpret_cast<float *>(c.gbuf);        // N + N/16 floats
   float *feat = spec + spec_phys(N);                      // CRN_MAX_BANDS floats
   if constexpr (G::XWAVE) __syncthreads();
-  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else wave_sync();
 #pragma unroll
   for (int j = 0; j < J; j++)
 #pragma unroll
@@ -360,7 +454,7 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
       spec[spec_phys(k)] = acc[j * R3 + d];
     }
   if constexpr (G::XWAVE) __syncthreads();
-  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else wave_sync();
 
   if (p.spectrum != nullptr && active) {
     float *dst = p.spectrum + epoch * N;
@@ -386,7 +480,7 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
     }
   }
   if constexpr (G::XWAVE) __syncthreads();
-  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else wave_sync();
 
   if (!active) return;
 
@@ -397,13 +491,15 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
   if (p.decide == CRN_DECIDE_ANN_K) {
     if (t == 0) {
       // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
-      const double fb[5] = {0.0, (double)feat[0], (double)feat[1], (double)feat[2], (double)feat[3]};
+      const double f1 = (double)feat[0], f2 = (double)feat[1], f3 = (double)feat[2], f4 = (double)feat[3];
       double hid[6];
 #pragma unroll
       for (int j = 1; j <= 5; j++) {  // .cpp:214-220
         double s = p.ann_w_ih[0 * 6 + j];
-#pragma unroll
-        for (int i = 1; i <= 4; i++) s += fb[i] * p.ann_w_ih[i * 6 + j];
+        s += f1 * p.ann_w_ih[1 * 6 + j];
+        s += f2 * p.ann_w_ih[2 * 6 + j];
+        s += f3 * p.ann_w_ih[3 * 6 + j];
+        s += f4 * p.ann_w_ih[4 * 6 + j];
         hid[j] = 1.0 / (1.0 + exp(-s));
       }
       double o[4];
@@ -448,23 +544,23 @@ __global__ __launch_bounds__(256, OCC) void sense_kernel(const SenseParams p) {
 // ---------------------------------------------------------------------------------------------
 // launch dispatch
 // ---------------------------------------------------------------------------------------------
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL = 0>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL, bool PK>
 static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   using G = Geo<R3>;
   const unsigned grid = (unsigned)((p.n_epochs + G::GROUPS - 1) / G::GROUPS);
-  const size_t lds = ((size_t)G::GROUPS * NBUF * G::GROUP_CPLX + (TW2LDS ? 16 * R3 : 0)) * sizeof(float2);
+  const size_t lds = ((size_t)G::GROUPS * NBUF * G::GROUP_CPLX + (TW2LDS ? 16 * R3 : 0)) * sizeof(cx);
   if (grid == 0) return hipSuccess;
   const bool full = p.L == G::N;
-#define CRN_LAUNCH(MAGV, WINV)                                                                  \
-  do {                                                                                          \
-    auto kfn = full ? sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, true>  \
-                    : sense_kernel<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, false>; \
-    if (lds > 48 * 1024) {                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                   \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return e;                                                            \
-    }                                                                                           \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);                             \
+#define CRN_LAUNCH(MAGV, WINV)                                                                            \
+  do {                                                                                                    \
+    auto kfn = full ? sense_kernel<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, true, PK>>   \
+                    : sense_kernel<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, false, PK>>; \
+    if (lds > 48 * 1024) {                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      if (e != hipSuccess) return e;                                                                      \
+    }                                                                                                     \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);                                       \
   } while (0)
   if (mag && win) CRN_LAUNCH(true, true);
   else if (mag) CRN_LAUNCH(true, false);
@@ -475,22 +571,22 @@ static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_
 }
 
 // Kernel variants selectable through crn_sense_set_variant (A/B measurements; 0 = default).
-struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl; };
+struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
 static constexpr VariantDesc kVariants[] = {
-    /* 0 (unused) */ {0, 0, 0, 0, 0, 0},
-    /* 1 */ {1, 0, 0, 1, 4, 0},
-    /* 2 */ {2, 0, 0, 0, 2, 0},
-    /* 3 */ {1, 1, 0, 1, 3, 0},
-    /* 4 */ {2, 1, 0, 0, 2, 0},
-    /* 5 */ {1, 0, 1, 1, 4, 0},
-    /* 6 */ {2, 0, 1, 0, 2, 0},
-    /* 7 */ {1, 1, 1, 1, 3, 0},
-    /* 8 */ {2, 1, 1, 0, 2, 0},
-    /* 9 */ {2, 1, 1, 1, 2, 0},
-    /* 10 */ {1, 1, 1, 0, 2, 0},
-    /* 11 */ {2, 1, 1, 0, 2, 1},  // ablation: stream only
-    /* 12 */ {2, 1, 1, 0, 2, 2},  // ablation: compute only
-    /* 13 */ {1, 1, 1, 1, 4, 0},
+    /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
+    /* 1 */ {1, 0, 1, 1, 4, 0, 1},
+    /* 2 */ {2, 0, 1, 0, 2, 0, 1},
+    /* 3 */ {1, 1, 1, 1, 3, 0, 1},
+    /* 4 */ {2, 1, 1, 0, 2, 0, 1},
+    /* 5 */ {1, 0, 1, 1, 4, 0, 0},
+    /* 6 */ {2, 1, 1, 0, 2, 0, 0},
+    /* 7 */ {1, 1, 1, 1, 3, 0, 0},
+    /* 8 */ {1, 1, 1, 0, 3, 0, 1},
+    /* 9 */ {1, 1, 1, 0, 2, 0, 1},
+    /* 10 */ {1, 1, 0, 1, 3, 0, 1},
+    /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
+    /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
+    /* 13 */ {1, 1, 1, 1, 4, 0, 1},
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 8;
@@ -500,22 +596,22 @@ template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   if (variant <= 0 || variant > kNumVariants || R3 != 16) variant = kDefaultVariant;
   if constexpr (R3 != 16) {
-    return launch_rn<R3, 2, true, true, false, 2>(p, mag, win, stream);
+    return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
   } else {
     switch (variant) {
-      case 1: return launch_rn<R3, 1, false, false, true, 4>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 2, false, false, false, 2>(p, mag, win, stream);
-      case 3: return launch_rn<R3, 1, true, false, true, 3>(p, mag, win, stream);
-      case 4: return launch_rn<R3, 2, true, false, false, 2>(p, mag, win, stream);
-      case 5: return launch_rn<R3, 1, false, true, true, 4>(p, mag, win, stream);
-      case 6: return launch_rn<R3, 2, false, true, false, 2>(p, mag, win, stream);
-      case 7: return launch_rn<R3, 1, true, true, true, 3>(p, mag, win, stream);
-      case 8: return launch_rn<R3, 2, true, true, false, 2>(p, mag, win, stream);
-      case 9: return launch_rn<R3, 2, true, true, true, 2>(p, mag, win, stream);
-      case 10: return launch_rn<R3, 1, true, true, false, 2>(p, mag, win, stream);
-      case 11: return launch_rn<R3, 2, true, true, false, 2, 1>(p, mag, win, stream);
-      case 12: return launch_rn<R3, 2, true, true, false, 2, 2>(p, mag, win, stream);
-      case 13: return launch_rn<R3, 1, true, true, true, 4>(p, mag, win, stream);
+      case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 2, false, true, false, 2, 0, true>(p, mag, win, stream);
+      case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
+      case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
+      case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
+      case 6: return launch_rn<R3, 2, true, true, false, 2, 0, false>(p, mag, win, stream);
+      case 7: return launch_rn<R3, 1, true, true, true, 3, 0, false>(p, mag, win, stream);
+      case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
+      case 9: return launch_rn<R3, 1, true, true, false, 2, 0, true>(p, mag, win, stream);
+      case 10: return launch_rn<R3, 1, true, false, true, 3, 0, true>(p, mag, win, stream);
+      case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
+      case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
+      case 13: return launch_rn<R3, 1, true, true, true, 4, 0, true>(p, mag, win, stream);
     }
   }
   return hipErrorInvalidValue;
@@ -534,20 +630,21 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 
 int sense_num_variants() { return kNumVariants; }
 
-void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds) {
+void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) {
   if (variant <= 0 || variant > kNumVariants || fft_len != 4096) variant = kDefaultVariant;
   *nbuf = kVariants[variant].nbuf;
   *prefetch = kVariants[variant].prefetch;
   *nt = kVariants[variant].nt;
   *tw2lds = kVariants[variant].tw2lds;
+  *pk = kVariants[variant].pk;
 }
 
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block) {
   const int r3 = fft_len / 256;
   const int t = 16 * r3;
   const int groups = 256 / t;
-  int nbuf, pf, nt, tl;
-  sense_variant(fft_len, variant, &nbuf, &pf, &nt, &tl);
+  int nbuf, pf, nt, tl, pk;
+  sense_variant(fft_len, variant, &nbuf, &pf, &nt, &tl, &pk);
   *threads = 256;
   *epochs_per_block = groups;
   *lds_bytes = (groups * nbuf * 16 * (t + r3) + (tl ? 16 * r3 : 0)) * 8;

@@ -180,17 +180,21 @@ def test_kernel_variants_agree(built):
     n_epochs = 9
     iq, _ = signals.make_epochs(cfg, n_epochs, seed=77)
     base = None
-    for v in range(0, 9):
+    for v in range(0, 14):
+        if v in (11, 12):
+            continue  # measurement ablations: not a sensing result
         s = cs.Sensor(cfg)
         s.set_variant(v)
         got = s.run_host(iq, n_epochs, want_spectrum=True)
         s.close()
         if base is None:
             base = got
+            truth = signals.spectrum_f64(cfg, iq, n_epochs)
         else:
-            # same arithmetic in every variant: bit-identical
-            assert np.array_equal(got["spectrum"], base["spectrum"]), v
-            assert np.array_equal(got["features"], base["features"]), v
+            # variants differ only in scheduling and in how twiddle products are rounded
+            assert per_bin_err(got["spectrum"], truth) < PER_BIN_TOL, v
+            assert np.allclose(got["features"], base["features"], rtol=2e-6, atol=0), v
+            assert np.array_equal(got["occupancy"], base["occupancy"]), v
 
 
 def test_power_of_two_scaling_is_exact(built):

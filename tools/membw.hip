@@ -46,7 +46,14 @@ int main() {
   void *d; float *out;
   CK(hipMalloc(&d, bytes)); CK(hipMalloc(&out, 4));
   CK(hipMemset(d, 1, bytes));
-  for (int blocks : {256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 32}) {
+  // bytes in flight per CU = blocks/CU * 256 threads * UNROLL * bytes per load
+  for (int blocks : {256, 512, 768, 1024}) {
+    printf("blocks=%5d x2/nt: u1 %6.0f  u2 %6.0f  u4 %6.0f  u8 %6.0f  u16 %6.0f  u32 %6.0f GB/s (in flight/CU: %d,%d,%d,%d,%d,%d KiB)\n", blocks,
+           run<v2f, 1, true>(d, bytes, out, blocks), run<v2f, 2, true>(d, bytes, out, blocks), run<v2f, 4, true>(d, bytes, out, blocks),
+           run<v2f, 8, true>(d, bytes, out, blocks), run<v2f, 16, true>(d, bytes, out, blocks), run<v2f, 32, true>(d, bytes, out, blocks),
+           blocks / 256 * 2, blocks / 256 * 4, blocks / 256 * 8, blocks / 256 * 16, blocks / 256 * 32, blocks / 256 * 64);
+  }
+  for (int blocks : {256 * 2, 256 * 8, 256 * 32}) {
     printf("blocks=%5d  x2/u4 %7.0f  x2/u16 %7.0f  x2/u16/nt %7.0f  x4/u4 %7.0f  x4/u8 %7.0f  x4/u8/nt %7.0f GB/s\n", blocks,
            run<v2f, 4, false>(d, bytes, out, blocks), run<v2f, 16, false>(d, bytes, out, blocks),
            run<v2f, 16, true>(d, bytes, out, blocks), run<v4f, 4, false>(d, bytes, out, blocks),
