@@ -34,13 +34,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def shard(n_total, rank, world):
-    """Contiguous stream shard [lo, hi) of rank `rank`."""
-    base, rem = divmod(n_total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +54,7 @@ def main():
     import torch.distributed as dist
 
     import crnsense as cs
+    from sharding import gather_occupancy, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +108,7 @@ def main():
     def step():
         sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
         if world > 1:
-            dist.all_gather_into_tensor(occ_all, occ)
+            gather_occupancy(occ, occ_all)
 
     for _ in range(args.warmup):
         step()
@@ -134,7 +128,7 @@ def main():
         if world > 1 or args.per_launch_events:
             ev[i][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(occ_all, occ)
+            gather_occupancy(occ, occ_all)
     span[1].record()
     torch.cuda.synchronize()
     if world > 1:

@@ -1,0 +1,144 @@
+// CE_Predictive_Node_GPU.cpp — see the header.  Control flow follows the reference's execute()
+// (cognitive_engines/CE_Predictive_Node/CE_Predictive_Node.cpp:54-292) statement for statement;
+// the arithmetic of lines 148-261 is one call into libcrnsense per epoch.
+#include "CE_Predictive_Node_GPU.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+// constructor (reference: CE_Predictive_Node.cpp:18-46)
+CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, ExtensibleCognitiveRadio *_ECR) {
+  ECR = _ECR;
+
+  fft_counter = 0;
+  config = 0;
+  sensor = NULL;
+  wall_clock_gate = true;
+  verbose = 1;
+  frame_len = 0;
+  decision = 0;
+  epochs_closed = 0;
+  memset(features, 0, sizeof(features));
+  memset(outputs, 0, sizeof(outputs));
+
+  crn_cfg_reference(&cfg);
+
+  // ce_args from the scenario file arrive as argv (reference: src/crts.cpp:43-81 str2argcargv,
+  // which resets optind; CE_Template.cpp:17-25 shows the getopt idiom)
+  int o;
+  optind = 1;
+  while ((o = getopt(argc, argv, "d:g:v:")) != EOF) {
+    switch (o) {
+    case 'd': cfg.device = atoi(optarg); break;           // HIP device ordinal
+    case 'g': wall_clock_gate = atoi(optarg) != 0; break;  // 0: sense continuously
+    case 'v': verbose = atoi(optarg); break;
+    }
+  }
+
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  sense_time_s = tv.tv_sec;
+  sense_time_us = tv.tv_usec;
+
+  // replaces memset of the three buffers + fft_create_plan (.cpp:36-45)
+  staging.assign((size_t)cfg.frames_per_epoch * cfg.fft_len, std::complex<float>(0.f, 0.f));
+  if (crn_sense_create(&cfg, &sensor) != CRN_OK) {
+    // the reference's convention for unrecoverable set-up errors (src/crts.cpp:111-115)
+    fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
+    exit(EXIT_FAILURE);
+  }
+}
+
+// destructor (reference: .cpp:49 — empty, and never run by the ECR)
+CE_Predictive_Node_GPU::~CE_Predictive_Node_GPU() { release(); }
+
+void CE_Predictive_Node_GPU::release() {
+  if (sensor) crn_sense_destroy(sensor);
+  sensor = NULL;
+}
+
+void CE_Predictive_Node_GPU::execute() {
+  // one-time radio configuration (.cpp:66-69); the weights of .cpp:78-120 live in cfg
+  if (config == 0) {
+    ECR->stop_tx();
+    ECR->set_rx_freq(Desired_fc);
+    ECR->set_rx_rate(Desired_BW);
+    config = 1;
+  }
+
+  // turn sensing on once the delay has passed (.cpp:127-141).  The reference adds the delay to
+  // tv_usec without carrying into tv_sec (.cpp:139-140); here the carry is done.
+  if (wall_clock_gate) {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    if ((tv.tv_sec > sense_time_s) || ((tv.tv_sec == sense_time_s) && (tv.tv_usec >= sense_time_us))) {
+      ECR->stop_tx();
+      ECR->set_ce_sensing(1);
+      long int us = tv.tv_usec + (long int)floorf(sensing_delay_ms * 1e3);
+      sense_time_s = tv.tv_sec + us / 1000000;
+      sense_time_us = us % 1000000;
+    }
+  } else if (fft_counter == 0 && !ECR->ce_sensing_flag) {
+    ECR->stop_tx();
+    ECR->set_ce_sensing(1);
+  }
+
+  // handle samples (.cpp:146)
+  if (ECR->CE_metrics.CE_event == ExtensibleCognitiveRadio::USRP_RX_SAMPS) {
+    const int N = cfg.fft_len, K = cfg.frames_per_epoch;
+    // .cpp:149 copies ce_usrp_rx_buffer_length samples unchecked; a packet longer than the FFT
+    // would overrun the reference's buffer — here it is truncated to N.
+    int L = ECR->ce_usrp_rx_buffer_length;
+    if (L > N) L = N;
+    if (L < 1) return;
+    if (fft_counter == 0) frame_len = L;
+    if (L != frame_len) L = L < frame_len ? L : frame_len;  // UHD packet size is constant in practice
+    std::complex<float> *dst = &staging[(size_t)fft_counter * frame_len];
+    memcpy(dst, ECR->ce_usrp_rx_buffer, (size_t)L * sizeof(std::complex<float>));
+    for (int i = L; i < frame_len; i++) dst[i] = std::complex<float>(0.f, 0.f);
+    fft_counter++;
+
+    if (fft_counter == K) {  // .cpp:157
+      ECR->set_ce_sensing(0);  // .cpp:159
+
+      // .cpp:150-154 for all K frames, .cpp:163-197, :200, :214-235, :245-261 — on the GPU
+      crn_out out;
+      memset(&out, 0, sizeof(out));
+      int32_t d = 0;
+      out.features = features;
+      out.ann_out = outputs;
+      out.decision = &d;
+      if (crn_sense_run_host(sensor, reinterpret_cast<const float *>(staging.data()), 1, frame_len, 0, &out) !=
+          CRN_OK) {
+        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
+        exit(EXIT_FAILURE);
+      }
+      decision = d;
+      epochs_closed++;
+
+      if (verbose) {  // .cpp:202-207, 239-261
+        printf("--------------------------------------------------------------\n");
+        printf("-            		FEATURES BUFFER 	               -\n");
+        printf("--------------------------------------------------------------\n");
+        printf("NOISE FLOOR   %.2e\nCH1           %.2e\nCH2           %.2e\nCH3           %.2e\n ", features[0],
+               features[1], features[2], features[3]);
+        printf("\n \n \n --------------------------------------------------------------\n");
+        printf("-            		 REAL TIME PREDICTION                  -\n");
+        printf("--------------------------------------------------------------\n");
+      }
+      if (d >= 1 && d <= 3) {
+        if (verbose)
+          printf("Channel_State[1]: %s \nChannel_State[2]: %s \nChannel_State[3]: %s \n \n \n",
+                 d == 1 ? "OCCUPIED" : "FREE", d == 2 ? "OCCUPIED" : "FREE", d == 3 ? "OCCUPIED" : "FREE");
+        ECR->set_tx_freq(cfg.tx_freq_for_decision[d]);  // .cpp:247,252,257
+      } else if (verbose) {
+        printf("ALL BUSY, SENSE AND OBSERVE AGAIN \n");  // .cpp:261
+      }
+
+      fft_counter = 0;  // .cpp:287-288 (fft_avg lives on the device and starts from zero each launch)
+    }
+  }
+}

@@ -1,0 +1,57 @@
+// CE_Predictive_Node_GPU — drop-in counterpart of the reference's CE_Predictive_Node
+// (cognitive_engines/CE_Predictive_Node/CE_Predictive_Node.{hpp,cpp}) whose per-epoch arithmetic
+// runs on an MI355X through libcrnsense's C ABI (include/crn_sense.h).
+//
+// Same plugin surface: constructor (argc, argv, ECR*), virtual execute(), state in through
+// ECR->CE_metrics / ce_usrp_rx_buffer, results out through the ECR setters.  Pure host C++11, so
+// CRTS's config_cognitive_engines registrar can pick the directory up unchanged
+// (reference: src/config_cognitive_engines.cpp:43-61,82-134); the only link addition is -lcrnsense.
+#ifndef _CE_PREDICTIVE_NODE_GPU_
+#define _CE_PREDICTIVE_NODE_GPU_
+
+#include <sys/time.h>
+
+#include <complex>
+#include <vector>
+
+#include "cognitive_engine.hpp"
+#include "extensible_cognitive_radio.hpp"
+#include "crn_sense.h"
+
+class CE_Predictive_Node_GPU : public CognitiveEngine {
+private:
+  // sensing parameters (reference: CE_Predictive_Node.hpp:30-33,42-43)
+  static constexpr float sensing_delay_ms = 1e2;
+  static constexpr float Desired_fc = 833e6;
+  static constexpr float Desired_BW = 13e6;
+
+  crn_cfg cfg;          // reference constants as data (crn_cfg_reference)
+  crn_handle *sensor;   // replaces `fftplan fft` (.hpp:78)
+  int config;           // first-call flag (.hpp:40)
+  int fft_counter;      // frames staged in the current epoch (.hpp:46)
+  long int sense_time_s, sense_time_us;  // next sensing start (.hpp:37-38)
+  bool wall_clock_gate; // -g 0 disables the gettimeofday gate (deterministic offline runs)
+  int verbose;          // -v 0 silences the reference's printf block
+  int frame_len;        // samples per staged packet, min(ce_usrp_rx_buffer_length, fft_len)
+
+  // K packets of the running epoch, frame-major, zero-padded per frame by the kernel.
+  // Replaces `float _Complex buffer[fft_length]` (.hpp:49): the reference transforms each packet
+  // as it arrives; this engine stages the epoch and transforms its K frames in one launch.
+  std::vector<std::complex<float> > staging;
+
+public:
+  // results of the last closed epoch (the reference only prints them: .cpp:202-261)
+  float features[4];    // NOISE_FLOOR, CH1, CH2, CH3
+  double outputs[3];    // Output[1..3]
+  int decision;         // 0 = "ALL BUSY", 1..3 = Channel_State[d] OCCUPIED
+  long epochs_closed;
+
+  CE_Predictive_Node_GPU(int argc, char **argv, ExtensibleCognitiveRadio *_ECR);
+  ~CE_Predictive_Node_GPU();
+  virtual void execute();
+  // The ECR never deletes its engine (no `delete CE` in the reference), so GPU resources are
+  // released explicitly or at process exit.
+  void release();
+};
+
+#endif

@@ -209,3 +209,37 @@ def test_power_of_two_scaling_is_exact(built):
     assert np.array_equal(4 * a["spectrum"], b["spectrum"])
     assert np.array_equal(4 * a["features"], b["features"])
     assert np.array_equal(a["occupancy"], b["occupancy"])
+
+
+@pytest.mark.parametrize("binary", ["engine_harness", "engine_harness_refbase"])
+def test_engine_drop_in_matches_reference_epoch(built, binary, tmp_path):
+    """The C++ engine behind the CognitiveEngine::execute() surface, driven packet by packet like
+    the ECR's rx/CE workers do, against the literal reference epoch of the oracle: same decisions,
+    same set_tx_freq arguments, same first-call configuration sequence.  The `_refbase` binary is
+    the same engine compiled against the reference's own cognitive_engine.hpp and linked with the
+    reference's own CognitiveEngine object code (built where /root/reference is mounted)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(cs.LIB_PATH), "host", binary)
+    if not os.path.exists(exe):
+        pytest.skip(f"{binary} was not built (reference tree absent at build time)")
+    cfg = cs.cfg_reference()
+    L, n_epochs = 364, 12
+    iq, picks = signals.make_epochs(cfg, n_epochs, seed=4242, L=L)
+    path = tmp_path / "iq.bin"
+    iq.tofile(path)
+    out = subprocess.run([exe, str(path), str(L), "-g", "0", "-v", "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("epoch")]
+    assert len(lines) == n_epochs
+    for e, w in enumerate(lines):
+        r = orc.ref_epoch(iq[e * 10 * L * 2:(e + 1) * 10 * L * 2], L)
+        assert int(w[3]) == r["decision"] == picks[e]
+        assert float(w[5]) == r["tx_freq"]
+        feat = np.array([float(x) for x in w[7:11]])
+        assert np.allclose(feat, r["features"], rtol=1e-5)
+        o = np.array([float(x) for x in w[12:15]])
+        assert np.abs(o - r["ann_out"]).max() < 1e-6
+    calls = [ln for ln in out.stdout.splitlines() if ln.startswith("calls")][0]
+    # CE_Predictive_Node.cpp:66-69 then :133-134
+    assert calls.startswith("calls stop_tx(0) set_rx_freq(8.33e+08) set_rx_rate(1.3e+07) stop_tx(0) set_ce_sensing(1)")
