@@ -19,6 +19,7 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   wall_clock_gate = true;
   verbose = 1;
   frame_len = 0;
+  sensing_on = 0;
   decision = 0;
   epochs_closed = 0;
   memset(features, 0, sizeof(features));
@@ -77,13 +78,15 @@ void CE_Predictive_Node_GPU::execute() {
     if ((tv.tv_sec > sense_time_s) || ((tv.tv_sec == sense_time_s) && (tv.tv_usec >= sense_time_us))) {
       ECR->stop_tx();
       ECR->set_ce_sensing(1);
+      sensing_on = 1;
       long int us = tv.tv_usec + (long int)floorf(sensing_delay_ms * 1e3);
       sense_time_s = tv.tv_sec + us / 1000000;
       sense_time_us = us % 1000000;
     }
-  } else if (fft_counter == 0 && !ECR->ce_sensing_flag) {
+  } else if (fft_counter == 0 && !sensing_on) {
     ECR->stop_tx();
     ECR->set_ce_sensing(1);
+    sensing_on = 1;
   }
 
   // handle samples (.cpp:146)
@@ -103,6 +106,7 @@ void CE_Predictive_Node_GPU::execute() {
 
     if (fft_counter == K) {  // .cpp:157
       ECR->set_ce_sensing(0);  // .cpp:159
+      sensing_on = 0;
 
       // .cpp:150-154 for all K frames, .cpp:163-197, :200, :214-235, :245-261 — on the GPU
       crn_out out;

@@ -32,6 +32,7 @@ private:
   long int sense_time_s, sense_time_us;  // next sensing start (.hpp:37-38)
   bool wall_clock_gate; // -g 0 disables the gettimeofday gate (deterministic offline runs)
   int verbose;          // -v 0 silences the reference's printf block
+  int sensing_on;       // what this engine last told set_ce_sensing (the ECR's own flag is private)
   int frame_len;        // samples per staged packet, min(ce_usrp_rx_buffer_length, fft_len)
 
   // K packets of the running epoch, frame-major, zero-padded per frame by the kernel.
