@@ -196,6 +196,15 @@ CRN_DEV void load_frame(cx (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
   for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, frame_soff + (unsigned)(T * r * 8));
 }
 
+// Half a frame: h[r] = x[t + T r], r = 0..7, of the N/2 samples starting `half_soff` bytes into the
+// window (Welch mode: consecutive frames share a half, so each half is fetched once).
+template <int R3, bool NT>
+CRN_DEV void load_half(cx (&h)[8], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned half_soff) {
+  constexpr int T = Geo<R3>::T;
+#pragma unroll
+  for (int r = 0; r < 8; r++) h[r] = ld_iq<NT>(rsrc, voff, half_soff + (unsigned)(T * r * 8));
+}
+
 // Zero padding of a short frame (L < N), applied when the registers are consumed (reference: the
 // FFT input buffer is zeroed once and only its first L entries are rewritten,
 // CE_Predictive_Node.cpp:37,149).
@@ -227,8 +236,9 @@ CRN_DEV void wave_sync() {
 //   PK       packed-f32 butterflies (see M<PK>)
 // ---------------------------------------------------------------------------------------------
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
-          bool FULL_, bool PK_>
+          bool FULL_, bool PK_, int OPT_ = 0>
 struct Cfg {
+  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the frame's compute
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
@@ -244,7 +254,7 @@ struct FrameCtx {
   const cx *tw2_lds;
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
-  float Kf;
+  float Kf, invK;
 };
 
 // One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` holds x[t + T r]
@@ -327,8 +337,11 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     if constexpr (C::MAG) {
-      const float mag = __fsqrt_rn(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
-      c.acc[i] += __fdiv_rn(mag, c.Kf);
+      // |X| / K per frame.  v_sqrt_f32 (1 ulp) and a multiply by 1/K instead of the reference's
+      // correctly rounded hypotf and divide: each addend moves by <= 2 ulp, five orders of
+      // magnitude inside the 1e-5 feature tolerance, at a fifth of the instructions.
+      const float mag = __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+      c.acc[i] = fmaf(mag, c.invK, c.acc[i]);
     } else {
       c.acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, c.acc[i]));
     }
@@ -350,99 +363,30 @@ CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]
 }
 
 // ---------------------------------------------------------------------------------------------
-// the sensing kernel
+// Epoch close (reference .cpp:157-261 + the reset at :287-288): K-frame averages -> LDS in natural
+// bin order -> band sums -> features -> decision.  Resets the accumulators for the next epoch.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p) {
-  constexpr int R3 = C::R3, NBUF = C::NBUF;
-  constexpr bool NT = C::NT, MAG = C::MAG;
+CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, bool active) {
+  constexpr int R3 = C::R3;
+  constexpr bool MAG = C::MAG;
   using G = Geo<R3>;
   constexpr int T = G::T, N = G::N, J = G::J;
-  extern __shared__ __attribute__((aligned(16))) cx lds[];
-
-  const int tid = threadIdx.x;
-  const int grp = tid / T;
-  const int t = tid % T;       // pass-1 column, n_lo
-  const int a = t / R3;        // pass-2/3 sub-transform id (k mod 16)
-  const int m_lo = t % R3;     // pass-2 column / pass-3 slot g
-  const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
-  const bool active = epoch < p.n_epochs;
-
-  FrameCtx<C> c;
-  c.t = t;
-  c.a = a;
-  c.m_lo = m_lo;
-  c.L = p.L;
-  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
-  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
-  const int K = p.K;
-  c.Kf = (float)K;
-
-  // frame-invariant twiddles, kept in registers across the K frames
-#pragma unroll
-  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
-  if constexpr (C::TW2LDS) {
-    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
-    __syncthreads();
-  } else {
-#pragma unroll
-    for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
-  }
-  if constexpr (C::WIN) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
-
-  // window of this workgroup: epochs [blockIdx.x * GROUPS, +GROUPS), clipped at the batch end
-  const long long first = (long long)blockIdx.x * G::GROUPS * p.epoch_stride;
-  // bytes this workgroup may touch (< 2 GiB, checked by the host): anything past it reads as zero
-  long long left = (p.total_samples - first) * 8;
-  const long long window = ((long long)G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + N) * 8;
-  if (left > window) left = window;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
-  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
-  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * 8u;
-  const unsigned fbytes = (unsigned)p.frame_stride * 8u;
-
-  cx ua[16], ub[16];
-  [[maybe_unused]] cx u0[16];
-  load_frame<R3, NT>(ua, rsrc, voff, 0u);
-  if constexpr (C::ABL == 2) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) u0[r] = ua[r];
-  }
-
-  if constexpr (C::PREFETCH && C::ABL != 2) {
-    // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
-    // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
-    // last frame they point outside the window and fetch nothing.
-    int f = 0;
-    for (; f + 1 < K; f += 2) {
-      load_frame<R3, NT>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
-      frame_step<C>(ua, c, f, u0);
-      load_frame<R3, NT>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
-      frame_step<C>(ub, c, f + 1, u0);
-    }
-    if (f < K) frame_step<C>(ua, c, f, u0);
-  } else {
-    for (int f = 0; f < K; f++) {
-      frame_step<C>(ua, c, f, u0);
-      if constexpr (C::ABL != 2)
-        load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
-    }
-  }
-
-  // ---------------- epoch close: spectrum -> LDS (natural order, padded) ----------------
   float (&acc)[16] = c.acc;
   const float Kf = c.Kf;
+  // Re-derive the lane coordinates behind an opaque move: otherwise the compiler hoists this
+  // block's address arithmetic out of the frame loop and keeps (or spills) ~40 registers for a
+  // block that runs once per K frames.
+  int t = c.t;
+  asm volatile("" : "+v"(t));
+  const int a = t / R3, m_lo = t % R3;
   if constexpr (!MAG) {
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = __fdiv_rn(acc[i], Kf);
   }
-  float *spec = reinterpret_cast<float *>(c.gbuf);        // N + N/16 floats
+  cx *gb = c.gbuf;
+  asm volatile("" : "+v"(gb));
+  float *spec = reinterpret_cast<float *>(gb);            // N + N/16 floats
   float *feat = spec + spec_phys(N);                      // CRN_MAX_BANDS floats
   if constexpr (G::XWAVE) __syncthreads();
   else wave_sync();
@@ -453,6 +397,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       const int k = a + 16 * (m_lo * J + j) + 256 * d;
       spec[spec_phys(k)] = acc[j * R3 + d];
     }
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;  // .cpp:287
   if constexpr (G::XWAVE) __syncthreads();
   else wave_sync();
 
@@ -462,7 +408,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     for (int r = 0; r < 16; r++) dst[t + T * r] = spec[spec_phys(t + T * r)];
   }
 
-  // ---------------- band sums (reference .cpp:173-191), one team of lanes per band ----------------
+  // band sums (reference .cpp:173-191), one team of lanes per band
   {
     constexpr int TEAM = G::TEAM;
     constexpr int TEAMS = T / TEAM;
@@ -482,92 +428,232 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   if constexpr (G::XWAVE) __syncthreads();
   else wave_sync();
 
-  if (!active) return;
+  if (active) {
+    if (p.features != nullptr)
+      for (int b = t; b < p.n_bands; b += T) p.features[epoch * p.n_bands + b] = feat[b];
 
-  if (p.features != nullptr)
-    for (int b = t; b < p.n_bands; b += T) p.features[epoch * p.n_bands + b] = feat[b];
-
-  // ---------------- decision ----------------
-  if (p.decide == CRN_DECIDE_ANN_K) {
-    if (t == 0) {
-      // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
-      const double f1 = (double)feat[0], f2 = (double)feat[1], f3 = (double)feat[2], f4 = (double)feat[3];
-      double hid[6];
+    if (p.decide == CRN_DECIDE_ANN_K) {
+      if (t == 0) {
+        // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
+        const double f1 = (double)feat[0], f2 = (double)feat[1], f3 = (double)feat[2], f4 = (double)feat[3];
+        double hid[6];
 #pragma unroll
-      for (int j = 1; j <= 5; j++) {  // .cpp:214-220
-        double s = p.ann_w_ih[0 * 6 + j];
-        s += f1 * p.ann_w_ih[1 * 6 + j];
-        s += f2 * p.ann_w_ih[2 * 6 + j];
-        s += f3 * p.ann_w_ih[3 * 6 + j];
-        s += f4 * p.ann_w_ih[4 * 6 + j];
-        hid[j] = 1.0 / (1.0 + exp(-s));
-      }
-      double o[4];
+        for (int j = 1; j <= 5; j++) {  // .cpp:214-220
+          double s = p.ann_w_ih[0 * 6 + j];
+          s += f1 * p.ann_w_ih[1 * 6 + j];
+          s += f2 * p.ann_w_ih[2 * 6 + j];
+          s += f3 * p.ann_w_ih[3 * 6 + j];
+          s += f4 * p.ann_w_ih[4 * 6 + j];
+          hid[j] = 1.0 / (1.0 + exp(-s));
+        }
+        double o[4];
 #pragma unroll
-      for (int k = 1; k <= 3; k++) {  // .cpp:229-235
-        double s = p.ann_w_ho[0 * 4 + k];
+        for (int k = 1; k <= 3; k++) {  // .cpp:229-235
+          double s = p.ann_w_ho[0 * 4 + k];
 #pragma unroll
-        for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
-        o[k] = 1.0 / (1.0 + exp(-s));
+          for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
+          o[k] = 1.0 / (1.0 + exp(-s));
+        }
+        // .cpp:245-261 cascade
+        int d = 0;
+        if (o[1] >= p.ann_threshold) d = 1;
+        else if (o[2] >= p.ann_threshold) d = 2;
+        else if (o[3] >= p.ann_threshold) d = 3;
+        if (p.ann_out != nullptr) {
+          p.ann_out[epoch * 3 + 0] = o[1];
+          p.ann_out[epoch * 3 + 1] = o[2];
+          p.ann_out[epoch * 3 + 2] = o[3];
+        }
+        if (p.decision != nullptr) p.decision[epoch] = d;
+        if (p.occupancy != nullptr)
+          for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
       }
-      // .cpp:245-261 cascade
-      int d = 0;
-      if (o[1] >= p.ann_threshold) d = 1;
-      else if (o[2] >= p.ann_threshold) d = 2;
-      else if (o[3] >= p.ann_threshold) d = 3;
-      if (p.ann_out != nullptr) {
-        p.ann_out[epoch * 3 + 0] = o[1];
-        p.ann_out[epoch * 3 + 1] = o[2];
-        p.ann_out[epoch * 3 + 2] = o[3];
-      }
-      if (p.decision != nullptr) p.decision[epoch] = d;
+    } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
+      const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
       if (p.occupancy != nullptr)
-        for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
+        for (int b = t; b < p.n_bands; b += T)
+          p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > p.thresh[b] * ref);
+      if (t == 0 && p.decision != nullptr) {
+        int cnt = 0;
+        for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > p.thresh[b] * ref) ? 1 : 0;
+        p.decision[epoch] = cnt;
+      }
+    } else {
+      if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
+      if (p.occupancy != nullptr)
+        for (int b = t; b < p.n_bands; b += T) p.occupancy[epoch * p.n_bands + b] = 0;
     }
-  } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
-    const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
-    if (p.occupancy != nullptr)
-      for (int b = t; b < p.n_bands; b += T)
-        p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > p.thresh[b] * ref);
-    if (t == 0 && p.decision != nullptr) {
-      int cnt = 0;
-      for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > p.thresh[b] * ref) ? 1 : 0;
-      p.decision[epoch] = cnt;
-    }
+  }
+  // the exchange buffers are reused by the next epoch's first frame
+  if constexpr (G::XWAVE) __syncthreads();
+  else wave_sync();
+}
+
+// Buffer resource over the IQ window of epoch group `eg` (GROUPS consecutive epochs): anything
+// past the window, or past the end of the batch, reads as zero.
+template <int R3>
+CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg) {
+  using G = Geo<R3>;
+  const long long first = eg * G::GROUPS * p.epoch_stride;
+  long long left = (p.total_samples - first) * 8;
+  const long long window = ((long long)G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * 8;
+  if (left > window) left = window;
+  if (left < 0) left = 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sensing kernel
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p) {
+  constexpr int R3 = C::R3, NBUF = C::NBUF;
+  constexpr bool NT = C::NT;
+  using G = Geo<R3>;
+  constexpr int T = G::T;
+  extern __shared__ __attribute__((aligned(16))) cx lds[];
+
+  const int tid = threadIdx.x;
+  const int grp = tid / T;
+  const int t = tid % T;       // pass-1 column, n_lo
+  const int a = t / R3;        // pass-2/3 sub-transform id (k mod 16)
+  const int m_lo = t % R3;     // pass-2 column / pass-3 slot g
+
+  FrameCtx<C> c;
+  c.t = t;
+  c.a = a;
+  c.m_lo = m_lo;
+  c.L = p.L;
+  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  const int K = p.K;
+  c.Kf = (float)K;
+  c.invK = 1.0f / (float)K;
+
+  // frame-invariant twiddles, kept in registers across frames and epochs
+#pragma unroll
+  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  if constexpr (C::TW2LDS) {
+    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
+    __syncthreads();
   } else {
-    if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
-    if (p.occupancy != nullptr)
-      for (int b = t; b < p.n_bands; b += T) p.occupancy[epoch * p.n_bands + b] = 0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
+  }
+  if constexpr (C::WIN) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
+
+  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
+  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * 8u;
+  const unsigned fbytes = (unsigned)p.frame_stride * 8u;
+
+  cx ua[16], ub[16];
+  [[maybe_unused]] cx u0[16];
+
+  {
+    const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
+    load_frame<R3, NT>(ua, rsrc, voff, 0u);
+    if constexpr (C::ABL == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) u0[r] = ua[r];
+    }
+    if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH) {
+      if (p.frame_stride * 2 == G::N) {
+        // Welch, hop = N/2: frame f = halves H(f) | H(f+1) with H(j) = samples [j N/2, (j+1) N/2).
+        // Three half-frame register sets: two hold the current frame's raw samples, the third
+        // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
+        // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
+        constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
+        cx h0[8], h1[8], hn[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          h0[r] = ua[r];
+          h1[r] = ua[8 + r];
+        }
+        for (int f = 0; f < K; f++) {
+          load_half<R3, NT>(hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            ub[r] = h0[r];
+            ub[8 + r] = h1[r];
+          }
+          frame_step<C>(ub, c, f, u0);
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            h0[r] = h1[r];
+            h1[r] = hn[r];
+          }
+        }
+        epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+        return;
+      }
+    }
+    if constexpr (C::PREFETCH && C::ABL != 2) {
+      // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
+      // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
+      // last frame they point outside the window and fetch nothing.
+      int f = 0;
+      for (; f + 1 < K; f += 2) {
+        load_frame<R3, NT>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+        if constexpr ((C::OPT & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+        frame_step<C>(ua, c, f, u0);
+        load_frame<R3, NT>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+        if constexpr ((C::OPT & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+        frame_step<C>(ub, c, f + 1, u0);
+      }
+      if (f < K) frame_step<C>(ua, c, f, u0);
+    } else {
+      for (int f = 0; f < K; f++) {
+        frame_step<C>(ua, c, f, u0);
+        if constexpr (C::ABL != 2)
+          load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
+      }
+    }
+    epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // launch dispatch
 // ---------------------------------------------------------------------------------------------
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL, bool PK>
-static hipError_t launch_rn(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
-  using G = Geo<R3>;
+template <class C>
+static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
+  using G = Geo<C::R3>;
   const unsigned grid = (unsigned)((p.n_epochs + G::GROUPS - 1) / G::GROUPS);
-  const size_t lds = ((size_t)G::GROUPS * NBUF * G::GROUP_CPLX + (TW2LDS ? 16 * R3 : 0)) * sizeof(cx);
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + (C::TW2LDS ? 16 * C::R3 : 0)) * sizeof(cx);
   if (grid == 0) return hipSuccess;
-  const bool full = p.L == G::N;
-#define CRN_LAUNCH(MAGV, WINV)                                                                            \
-  do {                                                                                                    \
-    auto kfn = full ? sense_kernel<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, true, PK>>   \
-                    : sense_kernel<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, ABL, false, PK>>; \
-    if (lds > 48 * 1024) {                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      if (e != hipSuccess) return e;                                                                      \
-    }                                                                                                     \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);                                       \
-  } while (0)
-  if (mag && win) CRN_LAUNCH(true, true);
-  else if (mag) CRN_LAUNCH(true, false);
-  else if (win) CRN_LAUNCH(false, true);
-  else CRN_LAUNCH(false, false);
-#undef CRN_LAUNCH
+  auto kfn = sense_kernel<C>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
   return hipGetLastError();
+}
+
+// Default configuration of every size: all mode / window / short-frame combinations.
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK>
+static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
+  const bool full = p.L == Geo<R3>::N;
+#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK>>(p, stream)
+  if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
+  if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
+  if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
+  if (full) CRN_GO(false, false, true);
+  CRN_GO(false, false, false);
+#undef CRN_GO
+}
+
+// A/B variants: compiled for the headline shape only (N = 4096, energy mode, no window, L = N).
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL, bool PK, int OPT = 0>
+static hipError_t launch_rn(const SenseParams &p, bool, bool, hipStream_t stream) {
+  return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, false, false, TW2LDS, OCC, ABL, true, PK, OPT>>(p, stream);
 }
 
 // Kernel variants selectable through crn_sense_set_variant (A/B measurements; 0 = default).
@@ -575,7 +661,7 @@ struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
 static constexpr VariantDesc kVariants[] = {
     /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
     /* 1 */ {1, 0, 1, 1, 4, 0, 1},
-    /* 2 */ {2, 0, 1, 0, 2, 0, 1},
+    /* 2 */ {1, 1, 1, 0, 3, 0, 1},  // = 8, prefetch loads pinned ahead of the compute
     /* 3 */ {1, 1, 1, 1, 3, 0, 1},
     /* 4 */ {2, 1, 1, 0, 2, 0, 1},
     /* 5 */ {1, 0, 1, 1, 4, 0, 0},
@@ -594,13 +680,15 @@ static constexpr int kDefaultVariant = 8;
 // The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
-  if (variant <= 0 || variant > kNumVariants || R3 != 16) variant = kDefaultVariant;
+  if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || win || p.L != Geo<R3>::N)
+    variant = kDefaultVariant;
   if constexpr (R3 != 16) {
-    return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
+    return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
   } else {
+    if (variant == kDefaultVariant) return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 2, false, true, false, 2, 0, true>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 1, true, true, false, 3, 0, true, 1>(p, mag, win, stream);
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
