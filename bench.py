@@ -4,8 +4,8 @@
 A "step" is one pass of the hot path (one kernel launch) over one batch of synthetic IQ that is
 already resident in HBM: `--epochs` decision epochs of K = 10 frames of N-point complex fp32.
 Default workload = the configuration the metric is quoted on (SURVEY.md §8d "cfgH"):
-4096-point FFT + energy detect, 3 channels + noise-floor band, threshold decision, 7168 epochs
-= 71 680 frames = 2.19 GiB of IQ per launch.
+4096-point FFT + energy detect, 3 channels + noise-floor band, threshold decision, 28 672 epochs
+= 286 720 frames = 8.75 GiB of IQ per launch (sized for 288 GB of HBM; 35x the Infinity Cache).
 
   python bench.py                     # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--fft", type=int, default=4096, help="FFT length N (headline: 4096)")
-    ap.add_argument("--epochs", type=int, default=7168, help="decision epochs per GPU per step")
+    ap.add_argument("--epochs", type=int, default=0, help="decision epochs per GPU per step (0 = 8.75 GiB of IQ)")
     ap.add_argument("--mode", choices=["energy", "ref", "welch"], default="energy")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip)")
@@ -82,8 +82,8 @@ def main():
         workload = f"{args.fft}-pt FFT + energy detect x 3ch (+noise-floor band), K=10, threshold"
     cfg.device = local_rank
     N, K = cfg.fft_len, cfg.frames_per_epoch
-    E = args.epochs                      # per GPU (weak scaling)
     spe = cs.samples_per_epoch(cfg)
+    E = args.epochs if args.epochs > 0 else (28672 * 40960) // spe   # per GPU (weak scaling)
     n_samples = cs.samples_needed(cfg, E)
     lo, hi = shard(E * world, rank, world)
     assert hi - lo == E
@@ -174,9 +174,9 @@ def main():
     if os.path.exists(args.traffic_json):
         try:
             tj = json.load(open(args.traffic_json))
-            key = f"{args.mode}{N}x{E}"
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
+            key = f"{args.mode}{N}"
+            if key in tj:  # measured once per kernel; scales linearly with the batch
+                traffic = int(tj[key]["hbm_bytes_per_launch"] * (E / tj[key]["epochs"]))
         except Exception:
             traffic = None
 
@@ -184,14 +184,15 @@ def main():
     if rank == 0 and world == 1 and args.cpu_epochs != 0:
         import oracle_py as orc
         cores = os.cpu_count() or 1
-        n_cpu = args.cpu_epochs if args.cpu_epochs > 0 else min(E, 64 * cores)
+        cap = max(1, (7168 * 40960) // spe)   # at most 2.2 GiB of the batch goes to the host
+        n_cpu = args.cpu_epochs if args.cpu_epochs > 0 else min(E, cap, 64 * cores)
         host_iq = iq[: cs.samples_needed(cfg, n_cpu) * 2].cpu().numpy()
         orc.run(cfg, host_iq, min(n_cpu, 2 * cores), n_threads=cores)  # warm-up (page in, plan)
         t1 = time.perf_counter()
         ref = orc.run(cfg, host_iq, n_cpu, n_threads=cores)
         t_cpu = time.perf_counter() - t1
         if args.cpu_epochs < 0 and t_cpu < 5.0:  # grow the sample to ~10 s of CPU work
-            n_cpu = int(min(E, n_cpu * 10.0 / max(t_cpu, 1e-3)))
+            n_cpu = int(min(E, cap, n_cpu * 10.0 / max(t_cpu, 1e-3)))
             host_iq = iq[: cs.samples_needed(cfg, n_cpu) * 2].cpu().numpy()
             t1 = time.perf_counter()
             ref = orc.run(cfg, host_iq, n_cpu, n_threads=cores)

@@ -238,7 +238,7 @@ CRN_DEV void wave_sync() {
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
           bool FULL_, bool PK_, int OPT_ = 0>
 struct Cfg {
-  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the frame's compute
+  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the compute; bit 1: frame pairs
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
@@ -257,55 +257,65 @@ struct FrameCtx {
   float Kf, invK;
 };
 
-// One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` holds x[t + T r]
-// on entry and is clobbered.
+// ---- phases of one frame; `u` holds x[t + T r] on entry -------------------------------------
+// pass 1: (zero pad, window,) DFT16 over r, twiddle W_N^{t a}
 template <class C>
-CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
-  constexpr int R3 = C::R3;
-  using G = Geo<R3>;
+CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c) {
   using m = M<C::PK>;
-  constexpr int ROW = G::ROW, J = G::J;
-  cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
-
-  if constexpr (!C::FULL) mask_frame<R3>(u, c.t, c.L);
+  if constexpr (!C::FULL) mask_frame<C::R3>(u, c.t, c.L);
   if constexpr (C::WIN) {
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
   }
-
-  // ---- pass 1: DFT16 over r, twiddle W_N^{t a} ----
-  cx v[16];
   dft16<C::PK>(u, v);
 #pragma unroll
   for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
-
-  // ---- exchange 1: [a][t] ----
-  if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();  // rows may still be read as exchange 2
+}
+// exchange 1, layout [a][t] with rows of T + R3 complex
+template <class C>
+CRN_DEV void ph_x1_write(const cx (&v)[16], cx *buf, FrameCtx<C> &c) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) buf[i * ROW + c.t] = v[i];
-  if constexpr (G::XWAVE) __syncthreads();
-  else wave_sync();
-  cx *row = buf + c.a * ROW;
+  for (int i = 0; i < 16; i++) buf[i * Geo<C::R3>::ROW + c.t] = v[i];
+}
+template <class C>
+CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
+  const cx *row = buf + c.a * Geo<C::R3>::ROW;
 #pragma unroll
-  for (int i = 0; i < 16; i++) u[i] = row[R3 * i + c.m_lo];
-
-  // ---- pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c} ----
+  for (int i = 0; i < 16; i++) u[i] = row[C::R3 * i + c.m_lo];
+}
+// pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c}
+template <class C>
+CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c) {
+  using m = M<C::PK>;
   dft16<C::PK>(u, v);
 #pragma unroll
-  for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], C::TW2LDS ? c.tw2_lds[i * R3 + c.m_lo] : c.tw2[i]);
-
-  // ---- exchange 2 (inside the R3 lanes sharing `a`): slot (c, m) at c*R3 + m + c/J ----
-  wave_sync();
+  for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], C::TW2LDS ? c.tw2_lds[i * C::R3 + c.m_lo] : c.tw2[i]);
+}
+// exchange 2, inside the R3 lanes sharing `a`: slot (c, m) at c*R3 + m + c/J of the group's own row
+template <class C>
+CRN_DEV void ph_x2_write(const cx (&v)[16], cx *buf, FrameCtx<C> &c) {
+  constexpr int R3 = C::R3, J = Geo<R3>::J;
+  cx *row = buf + c.a * Geo<R3>::ROW;
 #pragma unroll
   for (int cc = 0; cc < 16; cc++) row[cc * R3 + c.m_lo + cc / J] = v[cc];
-  wave_sync();
+}
+template <class C>
+CRN_DEV void ph_x2_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
+  constexpr int R3 = C::R3, J = Geo<R3>::J;
+  const cx *row = buf + c.a * Geo<R3>::ROW;
   // thread (a, g = m_lo) takes c = g*J + j, all m
 #pragma unroll
   for (int j = 0; j < J; j++)
 #pragma unroll
     for (int mm = 0; mm < R3; mm++) u[j * R3 + mm] = row[(c.m_lo * J + j) * R3 + mm + c.m_lo];
-
-  // ---- pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d lands in v[j*R3 + d] ----
+}
+// pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d; then the per-bin accumulate
+// over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K, CE_Predictive_Node.cpp:152-154)
+template <class C>
+CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+  constexpr int R3 = C::R3, J = Geo<R3>::J;
+  using m = M<C::PK>;
+  cx v[16];
   if constexpr (R3 == 16) {
     dft16<C::PK>(u, v);
   } else if constexpr (R3 == 8) {
@@ -332,8 +342,6 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
       v[j * 2 + 1] = m::sub(u[j * 2], u[j * 2 + 1]);
     }
   }
-
-  // ---- per-bin accumulate over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K) ----
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     if constexpr (C::MAG) {
@@ -349,8 +357,70 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
 }
 
 template <class C>
+CRN_DEV void group_sync() {
+  if constexpr (Geo<C::R3>::XWAVE) __syncthreads();
+  else wave_sync();
+}
+
+// One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` is clobbered.
+template <class C>
+CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
+  using G = Geo<C::R3>;
+  cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
+  cx v[16];
+  ph_pass1<C>(u, v, c);
+  if constexpr (C::ABL == 3) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) u[i] = v[i];
+    ph_pass2<C>(u, v, c);
+#pragma unroll
+    for (int i = 0; i < 16; i++) u[i] = v[i];
+  } else {
+    if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();  // rows may still be read as exchange 2
+    ph_x1_write<C>(v, buf, c);
+    group_sync<C>();
+    ph_x1_read<C>(u, buf, c);
+    ph_pass2<C>(u, v, c);
+    wave_sync();
+    ph_x2_write<C>(v, buf, c);
+    wave_sync();
+    ph_x2_read<C>(u, buf, c);
+  }
+  ph_pass3_acc<C>(u, c);
+}
+
+// Two frames of the same epoch in one instruction stream, each with its own LDS buffer: the
+// LDS writes / reads of one frame are in flight while the butterflies of the other issue, and the
+// pair shares its s_barriers (one per frame instead of two).  Needs NBUF == 2.
+template <class C>
+CRN_DEV void frame_pair_compute(cx (&ua)[16], cx (&ub)[16], FrameCtx<C> &c) {
+  using G = Geo<C::R3>;
+  static_assert(C::NBUF == 2, "the frame pair uses one exchange buffer per frame");
+  cx *bufa = c.gbuf, *bufb = c.gbuf + G::GROUP_CPLX;
+  cx va[16], vb[16];
+  ph_pass1<C>(ua, va, c);
+  group_sync<C>();               // every wave is done reading both buffers (previous pair)
+  ph_x1_write<C>(va, bufa, c);
+  ph_pass1<C>(ub, vb, c);        // butterflies of B while A's writes drain
+  ph_x1_write<C>(vb, bufb, c);
+  group_sync<C>();
+  ph_x1_read<C>(ua, bufa, c);
+  ph_x1_read<C>(ub, bufb, c);
+  ph_pass2<C>(ua, va, c);        // B's reads land meanwhile
+  wave_sync();
+  ph_x2_write<C>(va, bufa, c);
+  ph_pass2<C>(ub, vb, c);
+  ph_x2_write<C>(vb, bufb, c);
+  wave_sync();
+  ph_x2_read<C>(ua, bufa, c);
+  ph_x2_read<C>(ub, bufb, c);
+  ph_pass3_acc<C>(ua, c);
+  ph_pass3_acc<C>(ub, c);
+}
+
+template <class C>
 CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]) {
-  if constexpr (C::ABL == 2) {
+  if constexpr (C::ABL >= 2) {
 #pragma unroll
     for (int r = 0; r < 16; r++) cur[r] = cx{u0[r].x + (float)f * 1e-30f, u0[r].y};
   }
@@ -558,7 +628,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
     load_frame<R3, NT>(ua, rsrc, voff, 0u);
-    if constexpr (C::ABL == 2) {
+    if constexpr (C::ABL >= 2) {
 #pragma unroll
       for (int r = 0; r < 16; r++) u0[r] = ua[r];
     }
@@ -593,7 +663,35 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         return;
       }
     }
-    if constexpr (C::PREFETCH && C::ABL != 2) {
+    if constexpr ((C::OPT & 2) != 0 && C::ABL == 0 && C::NBUF == 2) {
+      // Frame pairs, two pairs per iteration in ping-pong: (ua, ub) and (uc, ud).
+      cx uc[16], ud[16];
+      load_frame<R3, NT>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
+      int f = 0;
+      for (; f + 3 < K; f += 4) {
+        load_frame<R3, NT>(uc, rsrc, voff, (unsigned)(f + 2) * fbytes);
+        load_frame<R3, NT>(ud, rsrc, voff, (unsigned)(f + 3) * fbytes);
+        frame_pair_compute<C>(ua, ub, c);
+        load_frame<R3, NT>(ua, rsrc, voff, f + 4 < K ? (unsigned)(f + 4) * fbytes : kNowhere);
+        load_frame<R3, NT>(ub, rsrc, voff, f + 5 < K ? (unsigned)(f + 5) * fbytes : kNowhere);
+        frame_pair_compute<C>(uc, ud, c);
+      }
+      const int rem = K - f;  // 0..3 frames left, the first two of them already in (ua, ub)
+      if (rem >= 2) {
+        load_frame<R3, NT>(uc, rsrc, voff, rem == 3 ? (unsigned)(f + 2) * fbytes : kNowhere);
+        frame_pair_compute<C>(ua, ub, c);
+        if (rem == 3) {
+          group_sync<C>();
+          frame_compute<C>(uc, c, 0);
+        }
+      } else if (rem == 1) {
+        group_sync<C>();
+        frame_compute<C>(ua, c, 0);
+      }
+      epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+      return;
+    }
+    if constexpr (C::PREFETCH && C::ABL < 2) {
       // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
       // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
       // last frame they point outside the window and fetch nothing.
@@ -610,7 +708,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     } else {
       for (int f = 0; f < K; f++) {
         frame_step<C>(ua, c, f, u0);
-        if constexpr (C::ABL != 2)
+        if constexpr (C::ABL < 2)
           load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
       }
     }
@@ -665,14 +763,16 @@ static constexpr VariantDesc kVariants[] = {
     /* 3 */ {1, 1, 1, 1, 3, 0, 1},
     /* 4 */ {2, 1, 1, 0, 2, 0, 1},
     /* 5 */ {1, 0, 1, 1, 4, 0, 0},
-    /* 6 */ {2, 1, 1, 0, 2, 0, 0},
+    /* 6 */ {2, 1, 1, 1, 2, 0, 1},  // frame pairs (two frames per wave in flight), tw2 in LDS
     /* 7 */ {1, 1, 1, 1, 3, 0, 0},
     /* 8 */ {1, 1, 1, 0, 3, 0, 1},
-    /* 9 */ {1, 1, 1, 0, 2, 0, 1},
+    /* 9 */ {2, 1, 1, 0, 2, 0, 1},  // frame pairs, tw2 in registers
     /* 10 */ {1, 1, 0, 1, 3, 0, 1},
     /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
     /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
     /* 13 */ {1, 1, 1, 1, 4, 0, 1},
+    /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: VALU only (no reload, no LDS exchange)
+    /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only at the default occupancy
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 8;
@@ -692,14 +792,16 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
-      case 6: return launch_rn<R3, 2, true, true, false, 2, 0, false>(p, mag, win, stream);
+      case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, 2>(p, mag, win, stream);
       case 7: return launch_rn<R3, 1, true, true, true, 3, 0, false>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
-      case 9: return launch_rn<R3, 1, true, true, false, 2, 0, true>(p, mag, win, stream);
+      case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, 2>(p, mag, win, stream);
       case 10: return launch_rn<R3, 1, true, false, true, 3, 0, true>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
       case 13: return launch_rn<R3, 1, true, true, true, 4, 0, true>(p, mag, win, stream);
+      case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
+      case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }
   }
   return hipErrorInvalidValue;
