@@ -24,6 +24,8 @@ EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
     "crn_synth_fill_device", "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
+    "crn_ingest_destroy",
     "crn_last_error", "crn_abi_version",
 ]
 
@@ -50,6 +52,12 @@ class Cfg(C.Structure):
 class Out(C.Structure):
     _fields_ = [("features", C.c_void_p), ("ann_out", C.c_void_p), ("decision", C.c_void_p),
                 ("occupancy", C.c_void_p), ("spectrum", C.c_void_p)]
+
+
+class EpochResult(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("decision", C.c_int32), ("epoch_seq", C.c_int64),
+                ("ann_out", C.c_double * 3), ("features", C.c_float * CRN_MAX_BANDS),
+                ("occupancy", C.c_uint8 * CRN_MAX_BANDS)]
 
 
 class CrnError(RuntimeError):
@@ -82,6 +90,12 @@ def lib():
         L.crn_sense_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
+        L.crn_ingest_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.crn_ingest_push.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.crn_ingest_flush.argtypes = [C.c_void_p]
+        L.crn_ingest_poll.argtypes = [C.c_void_p, C.POINTER(EpochResult), C.c_int32, C.POINTER(C.c_int32)]
+        L.crn_ingest_drain.argtypes = [C.c_void_p]
+        L.crn_ingest_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -182,3 +196,33 @@ class Sensor:
         check(lib().crn_synth_fill_device(self._h, iq_ptr, n_epochs, spe, seed, noise_power, signal_rms,
                                           tones, C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
               "crn_synth_fill_device")
+
+
+class Ingest:
+    """Packet ingest ring over a Sensor (crn_ingest_* in include/crn_sense.h)."""
+
+    def __init__(self, sensor, n_streams, samples_per_packet, epochs_per_batch):
+        self.sensor = sensor
+        self._g = C.c_void_p()
+        check(lib().crn_ingest_create(sensor._h, n_streams, samples_per_packet, epochs_per_batch,
+                                      C.byref(self._g)), "crn_ingest_create")
+
+    def push(self, stream, packet):
+        check(lib().crn_ingest_push(self._g, stream, packet.ctypes.data), "crn_ingest_push")
+
+    def flush(self):
+        check(lib().crn_ingest_flush(self._g), "crn_ingest_flush")
+
+    def drain(self):
+        check(lib().crn_ingest_drain(self._g), "crn_ingest_drain")
+
+    def poll(self, max_results=64):
+        arr = (EpochResult * max_results)()
+        n = C.c_int32()
+        check(lib().crn_ingest_poll(self._g, arr, max_results, C.byref(n)), "crn_ingest_poll")
+        return [arr[i] for i in range(n.value)]
+
+    def close(self):
+        if self._g:
+            lib().crn_ingest_destroy(self._g)
+            self._g = C.c_void_p()

@@ -183,6 +183,13 @@ int crn_sense_destroy(crn_handle *h) {
   return CRN_OK;
 }
 
+// internal (crn_ingest.cpp): the configuration a handle was created with
+int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) {
+  if (!h || !out) return crn::fail(CRN_ERR_ARG, "null handle");
+  *out = h->cfg;
+  return CRN_OK;
+}
+
 int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");

@@ -183,6 +183,39 @@ CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epo
 CRN_API int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs,
                        int32_t samples_per_frame, int64_t epoch_stride, const crn_out *out);
 
+/* -- ingest ring: the rx-worker side of the boundary --------------------------------------------
+ * The ECR's rx worker hands the engine one USRP packet at a time (memcpy into ce_usrp_rx_buffer +
+ * condition signal, src/extensible_cognitive_radio.cpp:1310-1324) and the engine must return
+ * quickly because CE_mutex is held (:1792-1803).  The ring coalesces packets of many streams into
+ * K-packet epochs in pinned host memory, ships full batches to the GPU asynchronously on a private
+ * stream (H2D -> kernel -> D2H, double buffered) and hands decisions back through a non-blocking
+ * poll, so `execute()` only ever copies one packet and checks a flag. */
+typedef struct crn_ingest crn_ingest;
+
+typedef struct crn_epoch_result {
+  int32_t stream;                    /* as given to crn_ingest_push                         */
+  int32_t decision;                  /* crn_out.decision                                    */
+  int64_t epoch_seq;                 /* 0, 1, 2, .. per stream                              */
+  double ann_out[3];                 /* DECIDE_ANN only                                     */
+  float features[CRN_MAX_BANDS];
+  uint8_t occupancy[CRN_MAX_BANDS];
+} crn_epoch_result;
+
+/* samples_per_packet: L of every pushed packet (1..fft_len; disjoint frames only).
+ * epochs_per_batch: completed epochs that trigger a launch. */
+CRN_API int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet,
+                              int32_t epochs_per_batch, crn_ingest **out);
+/* Copy one packet of stream `stream` (L interleaved complex samples).  Never blocks on the GPU
+ * unless both batch buffers are in flight (back-pressure). */
+CRN_API int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet);
+/* Launch the completed epochs staged so far, even if fewer than epochs_per_batch. */
+CRN_API int crn_ingest_flush(crn_ingest *g);
+/* Non-blocking: results of finished batches, oldest first.  *n_out <= max_results. */
+CRN_API int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, int32_t *n_out);
+/* flush + wait for everything in flight (results stay queued for crn_ingest_poll). */
+CRN_API int crn_ingest_drain(crn_ingest *g);
+CRN_API int crn_ingest_destroy(crn_ingest *g);
+
 /* -- measurement / test aids ------------------------------------------------------------- */
 
 /* Fill d_iq with n_epochs * samples_per_epoch seeded synthetic samples on the device:

@@ -303,3 +303,40 @@ def test_full_size_batch_properties(built):
     assert np.array_equal(feats.cpu().numpy(), 4 * f1)
     assert np.array_equal(occ.cpu().numpy(), o)
     s.close()
+
+
+def test_ingest_ring_many_streams(built):
+    """The rx-worker side: packets of several streams arrive interleaved, the ring coalesces them
+    into epochs, launches batches asynchronously and returns per-(stream, epoch) results that match
+    the literal reference epoch on the same packets."""
+    cfg = cs.cfg_reference()
+    S, n_ep, L, K = 5, 3, 364, 10
+    data = []
+    for st in range(S):
+        iq, picks = signals.make_epochs(cfg, n_ep, seed=500 + st, L=L)
+        data.append((iq.reshape(n_ep * K, L * 2), picks))
+    sensor = cs.Sensor(cfg)
+    ring = cs.Ingest(sensor, S, L, 4)
+    got = []
+    for pkt in range(n_ep * K):          # round-robin over streams, one packet each
+        for st in range(S):
+            ring.push(st, np.ascontiguousarray(data[st][0][pkt]))
+        got += ring.poll()
+    ring.drain()
+    got += ring.poll()
+    assert len(got) == S * n_ep
+    seen = set()
+    for r in got:
+        seen.add((r.stream, r.epoch_seq))
+        iq = data[r.stream][0][r.epoch_seq * K:(r.epoch_seq + 1) * K].ravel()
+        ref = orc.ref_epoch(iq, L)
+        assert r.decision == ref["decision"] == data[r.stream][1][r.epoch_seq]
+        assert np.allclose(np.array(r.features[:4]), ref["features"], rtol=1e-5)
+        assert np.abs(np.array(r.ann_out[:]) - ref["ann_out"]).max() < 1e-6
+    assert len(seen) == S * n_ep
+    # per stream the epochs come back in order
+    for st in range(S):
+        seqs = [r.epoch_seq for r in got if r.stream == st]
+        assert seqs == sorted(seqs)
+    ring.close()
+    sensor.close()
