@@ -16,6 +16,8 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   fft_counter = 0;
   config = 0;
   sensor = NULL;
+  ring = NULL;
+  async_mode = 0;
   wall_clock_gate = true;
   verbose = 1;
   frame_len = 0;
@@ -31,8 +33,9 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   // which resets optind; CE_Template.cpp:17-25 shows the getopt idiom)
   int o;
   optind = 1;
-  while ((o = getopt(argc, argv, "d:g:v:")) != EOF) {
+  while ((o = getopt(argc, argv, "a:d:g:v:")) != EOF) {
     switch (o) {
+    case 'a': async_mode = atoi(optarg); break;            // 1: enqueue + poll through the ingest ring
     case 'd': cfg.device = atoi(optarg); break;           // HIP device ordinal
     case 'g': wall_clock_gate = atoi(optarg) != 0; break;  // 0: sense continuously
     case 'v': verbose = atoi(optarg); break;
@@ -57,8 +60,36 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
 CE_Predictive_Node_GPU::~CE_Predictive_Node_GPU() { release(); }
 
 void CE_Predictive_Node_GPU::release() {
+  if (ring) crn_ingest_destroy(ring);
+  ring = NULL;
   if (sensor) crn_sense_destroy(sensor);
   sensor = NULL;
+}
+
+// The reference's report + action block (.cpp:202-261) for one closed epoch.
+void CE_Predictive_Node_GPU::report(const float *feat, const double *out3, int d) {
+  memcpy(features, feat, sizeof(features));
+  memcpy(outputs, out3, sizeof(outputs));
+  decision = d;
+  epochs_closed++;
+  if (verbose) {  // .cpp:202-207, 239-241
+    printf("--------------------------------------------------------------\n");
+    printf("-            		FEATURES BUFFER 	               -\n");
+    printf("--------------------------------------------------------------\n");
+    printf("NOISE FLOOR   %.2e\nCH1           %.2e\nCH2           %.2e\nCH3           %.2e\n ", features[0],
+           features[1], features[2], features[3]);
+    printf("\n \n \n --------------------------------------------------------------\n");
+    printf("-            		 REAL TIME PREDICTION                  -\n");
+    printf("--------------------------------------------------------------\n");
+  }
+  if (d >= 1 && d <= 3) {
+    if (verbose)
+      printf("Channel_State[1]: %s \nChannel_State[2]: %s \nChannel_State[3]: %s \n \n \n",
+             d == 1 ? "OCCUPIED" : "FREE", d == 2 ? "OCCUPIED" : "FREE", d == 3 ? "OCCUPIED" : "FREE");
+    ECR->set_tx_freq(cfg.tx_freq_for_decision[d]);  // .cpp:247,252,257
+  } else if (verbose) {
+    printf("ALL BUSY, SENSE AND OBSERVE AGAIN \n");  // .cpp:261
+  }
 }
 
 void CE_Predictive_Node_GPU::execute() {
@@ -89,6 +120,13 @@ void CE_Predictive_Node_GPU::execute() {
     sensing_on = 1;
   }
 
+  // asynchronous path: a decision launched by an earlier call may have landed
+  if (ring) {
+    crn_epoch_result r;
+    int32_t n = 0;
+    while (crn_ingest_poll(ring, &r, 1, &n) == CRN_OK && n == 1) report(r.features, r.ann_out, r.decision);
+  }
+
   // handle samples (.cpp:146)
   if (ECR->CE_metrics.CE_event == ExtensibleCognitiveRadio::USRP_RX_SAMPS) {
     const int N = cfg.fft_len, K = cfg.frames_per_epoch;
@@ -97,6 +135,27 @@ void CE_Predictive_Node_GPU::execute() {
     int L = ECR->ce_usrp_rx_buffer_length;
     if (L > N) L = N;
     if (L < 1) return;
+    if (async_mode && !ring) {
+      // one stream, one epoch per batch: the launch happens inside the K-th push, nothing waits
+      if (crn_ingest_create(sensor, 1, L, 1, &ring) != CRN_OK) {
+        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
+        exit(EXIT_FAILURE);
+      }
+    }
+    if (ring) {
+      if (L != frame_len && fft_counter != 0) return;  // UHD packet size is constant in practice
+      frame_len = L;
+      if (crn_ingest_push(ring, 0, reinterpret_cast<const float *>(ECR->ce_usrp_rx_buffer)) != CRN_OK) {
+        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
+        exit(EXIT_FAILURE);
+      }
+      if (++fft_counter == K) {
+        ECR->set_ce_sensing(0);  // .cpp:159; the decision is reported by a later execute()
+        sensing_on = 0;
+        fft_counter = 0;
+      }
+      return;
+    }
     if (fft_counter == 0) frame_len = L;
     if (L != frame_len) L = L < frame_len ? L : frame_len;  // UHD packet size is constant in practice
     std::complex<float> *dst = &staging[(size_t)fft_counter * frame_len];
@@ -112,35 +171,17 @@ void CE_Predictive_Node_GPU::execute() {
       crn_out out;
       memset(&out, 0, sizeof(out));
       int32_t d = 0;
-      out.features = features;
-      out.ann_out = outputs;
+      float feat[4];
+      double out3[3];
+      out.features = feat;
+      out.ann_out = out3;
       out.decision = &d;
       if (crn_sense_run_host(sensor, reinterpret_cast<const float *>(staging.data()), 1, frame_len, 0, &out) !=
           CRN_OK) {
         fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
         exit(EXIT_FAILURE);
       }
-      decision = d;
-      epochs_closed++;
-
-      if (verbose) {  // .cpp:202-207, 239-261
-        printf("--------------------------------------------------------------\n");
-        printf("-            		FEATURES BUFFER 	               -\n");
-        printf("--------------------------------------------------------------\n");
-        printf("NOISE FLOOR   %.2e\nCH1           %.2e\nCH2           %.2e\nCH3           %.2e\n ", features[0],
-               features[1], features[2], features[3]);
-        printf("\n \n \n --------------------------------------------------------------\n");
-        printf("-            		 REAL TIME PREDICTION                  -\n");
-        printf("--------------------------------------------------------------\n");
-      }
-      if (d >= 1 && d <= 3) {
-        if (verbose)
-          printf("Channel_State[1]: %s \nChannel_State[2]: %s \nChannel_State[3]: %s \n \n \n",
-                 d == 1 ? "OCCUPIED" : "FREE", d == 2 ? "OCCUPIED" : "FREE", d == 3 ? "OCCUPIED" : "FREE");
-        ECR->set_tx_freq(cfg.tx_freq_for_decision[d]);  // .cpp:247,252,257
-      } else if (verbose) {
-        printf("ALL BUSY, SENSE AND OBSERVE AGAIN \n");  // .cpp:261
-      }
+      report(feat, out3, d);
 
       fft_counter = 0;  // .cpp:287-288 (fft_avg lives on the device and starts from zero each launch)
     }

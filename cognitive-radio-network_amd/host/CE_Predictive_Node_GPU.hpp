@@ -27,10 +27,12 @@ private:
 
   crn_cfg cfg;          // reference constants as data (crn_cfg_reference)
   crn_handle *sensor;   // replaces `fftplan fft` (.hpp:78)
+  crn_ingest *ring;     // -a 1: asynchronous path, execute() only enqueues and polls
   int config;           // first-call flag (.hpp:40)
   int fft_counter;      // frames staged in the current epoch (.hpp:46)
   long int sense_time_s, sense_time_us;  // next sensing start (.hpp:37-38)
   bool wall_clock_gate; // -g 0 disables the gettimeofday gate (deterministic offline runs)
+  int async_mode;       // -a 1
   int verbose;          // -v 0 silences the reference's printf block
   int sensing_on;       // what this engine last told set_ce_sensing (the ECR's own flag is private)
   int frame_len;        // samples per staged packet, min(ce_usrp_rx_buffer_length, fft_len)
@@ -50,6 +52,7 @@ public:
   CE_Predictive_Node_GPU(int argc, char **argv, ExtensibleCognitiveRadio *_ECR);
   ~CE_Predictive_Node_GPU();
   virtual void execute();
+  void report(const float *feat, const double *out3, int d);  // print + set_tx_freq (.cpp:202-261)
   // The ECR never deletes its engine (no `delete CE` in the reference), so GPU resources are
   // released explicitly or at process exit.
   void release();

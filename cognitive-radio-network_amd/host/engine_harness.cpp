@@ -7,6 +7,7 @@
 // and finally the recorded setter-call sequence.
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
   ecr.CE->execute();
 
   long seen = 0;
+  long packets = 0;
   while (fread(buf.data(), sizeof(std::complex<float>), (size_t)L, f) == (size_t)L) {
     if (!ecr.ce_sensing_flag) {  // rx worker forwards packets only while sensing is on (:1310)
       ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::TIMEOUT;
@@ -49,6 +51,14 @@ int main(int argc, char **argv) {
     }
     ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::USRP_RX_SAMPS;  // :1320
     ecr.CE->execute();                                                  // :1802
+    packets++;
+    // in the asynchronous mode (-a 1) a decision lands on a later event: keep the CE worker's
+    // TIMEOUT events coming (ce_timeout_ms = 0 in scenarios/predictive_model.cfg:61) at epoch ends
+    for (int spin = 0; packets % 10 == 0 && engine->epochs_closed < packets / 10 && spin < 20000; spin++) {
+      usleep(50);
+      ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::TIMEOUT;
+      ecr.CE->execute();
+    }
     if (engine->epochs_closed != seen) {
       seen = engine->epochs_closed;
       double tx = 0.0;

@@ -211,8 +211,9 @@ def test_power_of_two_scaling_is_exact(built):
     assert np.array_equal(a["occupancy"], b["occupancy"])
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("binary", ["engine_harness", "engine_harness_refbase"])
-def test_engine_drop_in_matches_reference_epoch(built, binary, tmp_path):
+def test_engine_drop_in_matches_reference_epoch(built, binary, mode, tmp_path):
     """The C++ engine behind the CognitiveEngine::execute() surface, driven packet by packet like
     the ECR's rx/CE workers do, against the literal reference epoch of the oracle: same decisions,
     same set_tx_freq arguments, same first-call configuration sequence.  The `_refbase` binary is
@@ -228,7 +229,7 @@ def test_engine_drop_in_matches_reference_epoch(built, binary, tmp_path):
     iq, picks = signals.make_epochs(cfg, n_epochs, seed=4242, L=L)
     path = tmp_path / "iq.bin"
     iq.tofile(path)
-    out = subprocess.run([exe, str(path), str(L), "-g", "0", "-v", "0"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, str(path), str(L), "-g", "0", "-v", "0", "-a", mode], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("epoch")]
     assert len(lines) == n_epochs
