@@ -105,16 +105,24 @@ CRN_DEV void dft4(cx &a0, cx &a1, cx &a2, cx &a3) {
   a3 = m::sub_mj(d02, d13);  // d02 + j d13
 }
 
-// 16-point forward DFT, natural order in and out, as 4 x 4.
-template <bool PK>
-CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16]) {
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// 16-point forward DFT, natural order in and out, as 4 x 4.  `hook(k)`, k = 0..7, runs after the
+// k-th radix-4 group: the caller uses it to drop one prefetch load into the butterfly stream.
+template <bool PK, class Hook = NoHook>
+CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook()) {
   using m = M<PK>;
   cx y[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) y[i] = in[i];
   // level A: for each r0, DFT4 over r1 (r = r0 + 4 r1); a0 replaces r1
 #pragma unroll
-  for (int r0 = 0; r0 < 4; r0++) dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+  for (int r0 = 0; r0 < 4; r0++) {
+    dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+    hook(r0);
+  }
   // W16^{r0 a0} on element (r0, a0) = y[r0 + 4 a0]; W16^4 = -j is folded into level B
   const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
   const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
@@ -128,9 +136,13 @@ CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16]) {
   y[3 + 4 * 3] = m::mul_c(y[3 + 4 * 3], w9);
   // level B: for each a0, DFT4 over r0; X[a0 + 4 a1] = y[a1 + 4 a0]
   dft4<PK>(y[0], y[1], y[2], y[3]);
+  hook(4);
   dft4<PK>(y[4], y[5], y[6], y[7]);
+  hook(5);
   dft4<PK, true>(y[8], y[9], y[10], y[11]);  // y[10] carries the folded -j
+  hook(6);
   dft4<PK>(y[12], y[13], y[14], y[15]);
+  hook(7);
 #pragma unroll
   for (int a0 = 0; a0 < 4; a0++)
 #pragma unroll
@@ -238,7 +250,8 @@ CRN_DEV void wave_sync() {
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
           bool FULL_, bool PK_, int OPT_ = 0>
 struct Cfg {
-  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the compute; bit 1: frame pairs
+  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the compute; bit 1: frame pairs;
+                                    // bit 2: prefetch loads spread through the butterfly stream
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
@@ -257,17 +270,45 @@ struct FrameCtx {
   float Kf, invK;
 };
 
+// Drops the next frame's loads into the current frame's butterfly stream one at a time: a wave
+// that issues its 16 loads back to back sits on a full TA address FIFO for ~1000 cycles when HBM
+// is near saturation (SQ_VMEM_TA_ADDR_FIFO_FULL), and being in-order it cannot compute meanwhile.
+template <int R3, bool NT>
+struct SpreadLoads {
+  cx (&nx)[16];
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff, soff;
+  int pass;   // 0..2: which of the frame's three DFT16s this hook sits in
+  int plan;   // how the 16 loads are spread over the hook points
+  __device__ __forceinline__ void one(int idx) const {
+    __builtin_amdgcn_sched_barrier(0);
+    nx[idx] = ld_iq<NT>(rsrc, voff, soff + (unsigned)(Geo<R3>::T * idx * 8));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void operator()(int k) const {
+    if (plan == 0) {         // 8 in pass 1, 8 in pass 2, one per radix-4 group
+      if (pass < 2) one(pass * 8 + k);
+    } else if (plan == 1) {  // all 16 in pass 1, two per radix-4 group
+      if (pass == 0) { one(2 * k); one(2 * k + 1); }
+    } else {                 // 12 in pass 1 (3 per two groups), 4 in pass 2
+      if (pass == 0) { one(k + (k >> 1)); if (k & 1) one(k + (k >> 1) + 1); }
+      else if (pass == 1 && (k & 1)) one(12 + (k >> 1));
+    }
+  }
+};
+
+
 // ---- phases of one frame; `u` holds x[t + T r] on entry -------------------------------------
 // pass 1: (zero pad, window,) DFT16 over r, twiddle W_N^{t a}
-template <class C>
-CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c) {
+template <class C, class Hook = NoHook>
+CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
   if constexpr (!C::FULL) mask_frame<C::R3>(u, c.t, c.L);
   if constexpr (C::WIN) {
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
   }
-  dft16<C::PK>(u, v);
+  dft16<C::PK>(u, v, hook);
 #pragma unroll
   for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
 }
@@ -284,10 +325,10 @@ CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   for (int i = 0; i < 16; i++) u[i] = row[C::R3 * i + c.m_lo];
 }
 // pass 2: DFT16 over m_hi, twiddle W_T^{m_lo c}
-template <class C>
-CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c) {
+template <class C, class Hook = NoHook>
+CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
-  dft16<C::PK>(u, v);
+  dft16<C::PK>(u, v, hook);
 #pragma unroll
   for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], C::TW2LDS ? c.tw2_lds[i * C::R3 + c.m_lo] : c.tw2[i]);
 }
@@ -363,11 +404,32 @@ CRN_DEV void group_sync() {
 }
 
 // One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` is clobbered.
-template <class C>
-CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f) {
+// With SPREAD the next frame (`nx`, at `soff_next`) is fetched from inside passes 1 and 2.
+template <class C, bool SPREAD = false>
+CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nullptr,
+                           __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), unsigned voff = 0,
+                           unsigned soff_next = 0) {
   using G = Geo<C::R3>;
+  using m = M<C::PK>;
   cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
   cx v[16];
+  if constexpr (SPREAD) {
+    static_assert(C::ABL == 0, "ablations use the plain path");
+    constexpr int PLAN = (C::OPT >> 3) & 3;
+    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, PLAN}, h2{*nx, rsrc, voff, soff_next, 1, PLAN};
+    ph_pass1<C>(u, v, c, h1);
+    if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();
+    ph_x1_write<C>(v, buf, c);
+    group_sync<C>();
+    ph_x1_read<C>(u, buf, c);
+    ph_pass2<C>(u, v, c, h2);
+    wave_sync();
+    ph_x2_write<C>(v, buf, c);
+    wave_sync();
+    ph_x2_read<C>(u, buf, c);
+    ph_pass3_acc<C>(u, c);
+    return;
+  }
   ph_pass1<C>(u, v, c);
   if constexpr (C::ABL == 3) {
 #pragma unroll
@@ -691,6 +753,17 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
       return;
     }
+    if constexpr ((C::OPT & 4) != 0 && C::ABL == 0 && C::PREFETCH) {
+      // Ping-pong as below, but frame f+1's loads are issued from inside frame f's butterflies.
+      int f = 0;
+      for (; f + 1 < K; f += 2) {
+        frame_compute<C, true>(ua, c, f, &ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+        frame_compute<C, true>(ub, c, f + 1, &ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+      }
+      if (f < K) frame_compute<C>(ua, c, f);
+      epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+      return;
+    }
     if constexpr (C::PREFETCH && C::ABL < 2) {
       // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
       // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
@@ -739,7 +812,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
-#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK>>(p, stream)
+#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, 4>>(p, stream)
   if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
   if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
   if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
@@ -764,18 +837,18 @@ static constexpr VariantDesc kVariants[] = {
     /* 4 */ {2, 1, 1, 0, 2, 0, 1},
     /* 5 */ {1, 0, 1, 1, 4, 0, 0},
     /* 6 */ {2, 1, 1, 1, 2, 0, 1},  // frame pairs (two frames per wave in flight), tw2 in LDS
-    /* 7 */ {1, 1, 1, 1, 3, 0, 0},
+    /* 7 */ {1, 1, 1, 0, 3, 0, 1},  // spread prefetch, plan 2 (12 + 4)
     /* 8 */ {1, 1, 1, 0, 3, 0, 1},
     /* 9 */ {2, 1, 1, 0, 2, 0, 1},  // frame pairs, tw2 in registers
-    /* 10 */ {1, 1, 0, 1, 3, 0, 1},
+    /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // = 8 with the prefetch loads spread through the butterflies
     /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
     /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
-    /* 13 */ {1, 1, 1, 1, 4, 0, 1},
+    /* 13 */ {1, 1, 1, 0, 3, 0, 1},  // spread prefetch, plan 1 (16 loads in pass 1)
     /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: VALU only (no reload, no LDS exchange)
     /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only at the default occupancy
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
-static constexpr int kDefaultVariant = 8;
+static constexpr int kDefaultVariant = 10;
 
 // The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
@@ -785,7 +858,8 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   if constexpr (R3 != 16) {
     return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
   } else {
-    if (variant == kDefaultVariant) return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
+    if (variant == kDefaultVariant && (mag || win || p.L != Geo<R3>::N))
+      return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
       case 2: return launch_rn<R3, 1, true, true, false, 3, 0, true, 1>(p, mag, win, stream);
@@ -793,13 +867,13 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
       case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, 2>(p, mag, win, stream);
-      case 7: return launch_rn<R3, 1, true, true, true, 3, 0, false>(p, mag, win, stream);
+      case 7: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 16>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
       case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, 2>(p, mag, win, stream);
-      case 10: return launch_rn<R3, 1, true, false, true, 3, 0, true>(p, mag, win, stream);
+      case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
-      case 13: return launch_rn<R3, 1, true, true, true, 4, 0, true>(p, mag, win, stream);
+      case 13: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 8>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }
