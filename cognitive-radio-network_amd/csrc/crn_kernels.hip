@@ -290,9 +290,11 @@ struct SpreadLoads {
       if (pass < 2) one(pass * 8 + k);
     } else if (plan == 1) {  // all 16 in pass 1, two per radix-4 group
       if (pass == 0) { one(2 * k); one(2 * k + 1); }
-    } else {                 // 12 in pass 1 (3 per two groups), 4 in pass 2
+    } else if (plan == 2) {  // 12 in pass 1 (3 per two groups), 4 in pass 2
       if (pass == 0) { one(k + (k >> 1)); if (k & 1) one(k + (k >> 1) + 1); }
       else if (pass == 1 && (k & 1)) one(12 + (k >> 1));
+    } else {                 // half a frame (Welch): 8 loads, one per radix-4 group of pass 1
+      if (pass == 0) one(k);
     }
   }
 };
@@ -437,7 +439,7 @@ CRN_DEV void group_sync() {
 
 // One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` is clobbered.
 // With SPREAD the next frame (`nx`, at `soff_next`) is fetched from inside passes 1 and 2.
-template <class C, bool SPREAD = false>
+template <class C, bool SPREAD = false, int PLAN_ = -1>
 CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nullptr,
                            __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), unsigned voff = 0,
                            unsigned soff_next = 0) {
@@ -447,7 +449,7 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
   cx v[16];
   if constexpr (SPREAD) {
     static_assert(C::ABL == 0, "ablations use the plain path");
-    constexpr int PLAN = (C::OPT >> 3) & 3;
+    constexpr int PLAN = PLAN_ >= 0 ? PLAN_ : (C::OPT >> 3) & 3;
     const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, PLAN}, h2{*nx, rsrc, voff, soff_next, 1, PLAN};
     ph_pass1<C>(u, v, c, h1);
     if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();
@@ -733,20 +735,20 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
         // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
         constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
-        cx h0[8], h1[8], hn[8];
+        cx h0[8], h1[8], hn[16];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
           h0[r] = ua[r];
           h1[r] = ua[8 + r];
         }
         for (int f = 0; f < K; f++) {
-          load_half<R3, NT>(hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             ub[r] = h0[r];
             ub[8 + r] = h1[r];
           }
-          frame_step<C>(ub, c, f, u0);
+          // H(f+2) is fetched from inside frame f's first pass, one load per radix-4 group
+          frame_compute<C, true, 3>(ub, c, f, &hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             h0[r] = h1[r];
