@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Copy the round's evidence from gpurun_out/r01 (scratch) into profiles/ (tracked) and derive
+profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes."""
+import collections, csv, glob, json, os, shutil, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(R, "gpurun_out", "r01")
+DST = os.path.join(R, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(DST, exist_ok=True)
+for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("bench_headline.json", f"{tag}_bench_headline.json"),
+                 ("bench_cfg1_1024.json", f"{tag}_bench_cfg1_1024pt.json"), ("bench_cfg3_ref512.json", f"{tag}_bench_cfg3_ref512.json"),
+                 ("bench_cfg2_welch.json", f"{tag}_bench_cfg2_welch.json"), ("host_rate.txt", f"{tag}_host_buffer_rate.txt"),
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("smoke.log", f"{tag}_smoke.log")):
+    m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
+    if m:
+        shutil.copy(m[-1], os.path.join(DST, dst))
+open(os.path.join(DST, f"{tag}_pmc_hbm_traffic.txt"), "w").write(
+    subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_summary.py"), SRC], capture_output=True, text=True).stdout)
+
+
+def mean_counter(sub, name):
+    f = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    if not f:
+        return None
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[-1]))
+         if "sense_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return sum(v[-5:]) / len(v[-5:]) if v else None
+
+
+fetch, write = mean_counter("pmc_fetch", "FETCH_SIZE"), mean_counter("pmc_write", "WRITE_SIZE")
+head = json.load(open(os.path.join(SRC, "bench_headline.json")))
+if fetch is not None:
+    E = head["config"]["epochs_per_gpu"]
+    out = {
+        "_how": "rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes "
+                "(--kernel-trace only) over `python3 bench.py --steps 5 --warmup 20 --cpu-epochs 0`; FETCH_SIZE is KiB and on "
+                "gfx950 tallies each 128-B request as 64 B, so x2 (MI355X_MICROARCH.md, HBM section); the x2 was re-calibrated for "
+                "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt)",
+        "energy4096": {"epochs": E, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                        "hbm_bytes_per_launch": int(fetch * 1024 * 2 + (write or 0) * 1024),
+                        "algorithmic_bytes_per_launch": head["config"]["bytes_per_gpu_per_step"]}}
+    json.dump(out, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
+    print(out["energy4096"])
+print(sorted(os.listdir(DST)))

@@ -8,9 +8,9 @@ cd $R
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 timeout 600 python bench.py > $O/bench_headline.json 2> $O/bench_headline.err
-timeout 300 python bench.py --fft 1024 --epochs 28672 > $O/bench_cfg1_1024.json 2> $O/bench_cfg1.err
-timeout 300 python bench.py --mode ref --epochs 57344 --cpu-epochs 0 > $O/bench_cfg3_ref512.json 2> $O/bench_cfg3.err
-timeout 300 python bench.py --mode welch --epochs 4096 --cpu-epochs 0 > $O/bench_cfg2_welch.json 2> $O/bench_cfg2.err
+timeout 300 python bench.py --fft 1024 > $O/bench_cfg1_1024.json 2> $O/bench_cfg1.err
+timeout 300 python bench.py --mode ref --cpu-epochs 0 > $O/bench_cfg3_ref512.json 2> $O/bench_cfg3.err
+timeout 300 python bench.py --mode welch --cpu-epochs 0 > $O/bench_cfg2_welch.json 2> $O/bench_cfg2.err
 timeout 300 python tools/host_rate.py > $O/host_rate.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --cpu-epochs 0 > $O/stats.log 2>&1
