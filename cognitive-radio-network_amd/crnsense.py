@@ -17,7 +17,7 @@ CRN_MAX_SEGS = 160
 
 MODE_REF_MAG, MODE_ENERGY = 0, 1
 DECIDE_ANN, DECIDE_THRESHOLD, DECIDE_NONE = 0, 1, 2
-WINDOW_RECT, WINDOW_HANN = 0, 1
+WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 
 # every symbol include/crn_sense.h declares (tests check the library exports them all)
 EXPORTS = [

@@ -54,7 +54,7 @@ int validate(const crn_cfg *c) {
   if (c->hop < 1 || c->hop > c->fft_len) return crn::fail(CRN_ERR_ARG, "hop out of range");
   if (c->mode != CRN_MODE_REF_MAG && c->mode != CRN_MODE_ENERGY) return crn::fail(CRN_ERR_ARG, "bad mode");
   if (c->decide < CRN_DECIDE_ANN || c->decide > CRN_DECIDE_NONE) return crn::fail(CRN_ERR_ARG, "bad decide");
-  if (c->window != CRN_WINDOW_RECT && c->window != CRN_WINDOW_HANN) return crn::fail(CRN_ERR_ARG, "bad window");
+  if (c->window < CRN_WINDOW_RECT || c->window > CRN_WINDOW_BLACKMAN_HARRIS) return crn::fail(CRN_ERR_ARG, "bad window");
   if (c->n_bands < 1 || c->n_bands > CRN_MAX_BANDS) return crn::fail(CRN_ERR_ARG, "n_bands out of range");
   if (c->n_segs < 1 || c->n_segs > CRN_MAX_SEGS) return crn::fail(CRN_ERR_ARG, "n_segs out of range");
   for (int s = 0; s < c->n_segs; s++) {
@@ -108,6 +108,11 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   std::vector<float> win(N, 1.0f);
   if (cfg->window == CRN_WINDOW_HANN)
     for (int n = 0; n < N; n++) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)N));
+  if (cfg->window == CRN_WINDOW_BLACKMAN_HARRIS)
+    for (int n = 0; n < N; n++) {
+      const double x = 2.0 * M_PI * (double)n / (double)(N - 1);
+      win[n] = (float)(0.35875 - 0.48829 * std::cos(x) + 0.14128 * std::cos(2 * x) - 0.01168 * std::cos(3 * x));
+    }
 
   // segments grouped by band, table order kept inside a band (the reference sums CH1's two runs
   // in table order, CE_Predictive_Node.cpp:173-179)

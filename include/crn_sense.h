@@ -74,7 +74,10 @@ typedef enum crn_decide {
 
 typedef enum crn_window {
   CRN_WINDOW_RECT = 0,   /* the reference applies no window (CE_Predictive_Node.cpp:149-150) */
-  CRN_WINDOW_HANN = 1    /* periodic Hann, w[n] = 0.5 - 0.5 cos(2 pi n / N) (Welch mode)     */
+  CRN_WINDOW_HANN = 1,   /* periodic Hann, w[n] = 0.5 - 0.5 cos(2 pi n / N) (Welch mode)     */
+  /* 4-term Blackman-Harris over N-1, a = {0.35875, 0.48829, 0.14128, 0.01168}: the window of the
+   * reference's GNU Radio monitor (spectrum_analyzer.py:262-275, firdes.WIN_BLACKMAN_hARRIS). */
+  CRN_WINDOW_BLACKMAN_HARRIS = 2
 } crn_window;
 
 /* Bins [lo, hi) of the N-point spectrum contribute to feature `band`. */

@@ -360,6 +360,13 @@ ORACLE_API int crn_oracle_run(const crn_cfg *c, const float *iq, int64_t n_epoch
   if (c->window == CRN_WINDOW_HANN) {
     win = (float *)malloc(sizeof(float) * (size_t)N);
     for (int i = 0; i < N; i++) win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)N));
+  } else if (c->window == CRN_WINDOW_BLACKMAN_HARRIS) {
+    /* spectrum_analyzer.py:262-275 (firdes.WIN_BLACKMAN_hARRIS): 4-term, symmetric over N-1 */
+    win = (float *)malloc(sizeof(float) * (size_t)N);
+    for (int i = 0; i < N; i++) {
+      const double x = 2.0 * M_PI * (double)i / (double)(N - 1);
+      win[i] = (float)(0.35875 - 0.48829 * cos(x) + 0.14128 * cos(2 * x) - 0.01168 * cos(3 * x));
+    }
   }
   if (n_threads < 1) n_threads = 1;
   int fail = 0;

@@ -62,6 +62,9 @@ def spectrum_f64(cfg, iq, n_epochs, L=None):
     w = np.ones(N)
     if cfg.window == 1:
         w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)).astype(np.float32).astype(np.float64)
+    elif cfg.window == 2:
+        th = 2 * np.pi * np.arange(N) / (N - 1)
+        w = (0.35875 - 0.48829 * np.cos(th) + 0.14128 * np.cos(2 * th) - 0.01168 * np.cos(3 * th)).astype(np.float32).astype(np.float64)
     out = np.zeros((n_epochs, N))
     for e in range(n_epochs):
         for f in range(K):

@@ -398,3 +398,14 @@ def test_explicit_epoch_stride_and_overlapping_epochs(built):
     assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
     truth = np.stack([signals.spectrum_f64(cfg, iq[2 * e * stride:2 * (e * stride + K * N)], 1)[0] for e in range(n_epochs)])
     assert per_bin_err(got["spectrum"], truth) < PER_BIN_TOL
+
+
+def test_blackman_harris_monitor_mode(built):
+    """The GNU Radio monitor's settings (spectrum_analyzer.py:29,262-275): 1024-point
+    Blackman-Harris PSD, disjoint frames, per-bin output; compared with float64 and the oracle."""
+    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    cfg.window = cs.WINDOW_BLACKMAN_HARRIS
+    cfg.decide = cs.DECIDE_NONE
+    n_epochs = 7
+    iq, _ = signals.make_epochs(cfg, n_epochs, seed=1024)
+    check_against_oracle(cfg, iq, n_epochs)
