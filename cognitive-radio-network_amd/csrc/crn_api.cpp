@@ -100,9 +100,10 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   h->cfg = *cfg;
 
   const int N = cfg->fft_len, R3 = N / 256, T = N / 16;
-  std::vector<float2> tw1((size_t)16 * T), tw2((size_t)16 * R3);
+  std::vector<float2> tw1((size_t)17 * T), tw2((size_t)16 * R3);  // row 16 of tw1: W_N^{16 t}
   for (int i = 0; i < 16; i++)
     for (int t = 0; t < T; t++) tw1[(size_t)i * T + t] = twiddle((long long)i * t, N);
+  for (int t = 0; t < T; t++) tw1[(size_t)16 * T + t] = twiddle(16LL * t, N);
   for (int i = 0; i < 16; i++)
     for (int m = 0; m < R3; m++) tw2[(size_t)i * R3 + m] = twiddle((long long)i * m, T);
   std::vector<float> win(N, 1.0f);

@@ -19,7 +19,7 @@ struct SenseParams {
   int L;                   // samples taken per frame (zero-padded to N)
   int K;                   // frames per epoch
   // tables (device, built at crn_sense_create)
-  const float2 *tw1;       // [16][T]  W_N^{t a}
+  const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}
   const float *window;     // [N] or null
   const int *band_seg_begin;  // [n_bands + 1] into seg_lo/seg_hi (segments grouped by band)

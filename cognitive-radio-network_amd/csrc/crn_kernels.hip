@@ -74,6 +74,18 @@ struct M {
       return cx{fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y)};
     }
   }
+  // a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+  CRN_DEV cx mul_conj(cx a, cx w) {
+    if constexpr (PK) {
+      cx t, d;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+          : "=v"(d) : "v"(a), "v"(w), "v"(t));
+      return d;
+    } else {
+      return cx{fmaf(a.y, w.y, a.x * w.x), fmaf(-a.x, w.y, a.y * w.x)};
+    }
+  }
   // a * w, w a wave-uniform constant held in an SGPR pair
   CRN_DEV cx mul_c(cx a, cx w) {
     if constexpr (PK) {
@@ -311,8 +323,17 @@ CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook
     for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
   }
   dft16<C::PK>(u, v, hook);
+  if constexpr ((C::OPT & 64) != 0) {
+    // compressed table: tw1[1..8] = W^{t i}, tw1[0] = W^{16 t}; W^{t (16-i)} = W^{16 t} conj(W^{t i})
 #pragma unroll
-  for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
+    for (int i = 1; i <= 8; i++) v[i] = m::mul(v[i], c.tw1[i]);
+#pragma unroll
+    for (int i = 9; i < 16; i++) v[i] = m::mul_conj(m::mul(v[i], c.tw1[0]), c.tw1[16 - i]);
+  } else {
+#pragma unroll
+    for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
+  }
+  if constexpr ((C::OPT & 128) != 0) __builtin_amdgcn_sched_barrier(0);
 }
 // exchange 1, layout [a][t] with rows of T + R3 complex
 template <class C>
@@ -698,7 +719,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 
   // frame-invariant twiddles, kept in registers across frames and epochs
 #pragma unroll
-  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  for (int i = 1; i < ((C::OPT & 64) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  if constexpr ((C::OPT & 64) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
     __syncthreads();
@@ -871,18 +893,18 @@ static constexpr VariantDesc kVariants[] = {
     /* 4 */ {2, 1, 1, 0, 2, 0, 1},
     /* 5 */ {1, 0, 1, 1, 4, 0, 0},
     /* 6 */ {2, 1, 1, 1, 2, 0, 1},  // frame pairs (two frames per wave in flight), tw2 in LDS
-    /* 7 */ {1, 1, 1, 0, 3, 0, 1},  // spread prefetch, plan 2 (12 + 4)
+    /* 7 */ {1, 1, 1, 1, 4, 0, 1},  // 4 workgroups per CU: compressed tw1, tw2 in LDS, spread prefetch
     /* 8 */ {1, 1, 1, 0, 3, 0, 1},
     /* 9 */ {2, 1, 1, 0, 2, 0, 1},  // frame pairs, tw2 in registers
     /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // = 8 + prefetch loads spread through the butterflies + ds_read_b64 blocks
     /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
     /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
-    /* 13 */ {1, 1, 1, 0, 3, 0, 1},  // spread prefetch, compiler-scheduled LDS reads
+    /* 13 */ {1, 1, 1, 1, 4, 0, 1},  // as 7 without the phase fences
     /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: VALU only (no reload, no LDS exchange)
     /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only at the default occupancy
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
-static constexpr int kDefaultVariant = 10;
+static constexpr int kDefaultVariant = 13;
 
 // The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
@@ -901,13 +923,13 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
       case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, 2>(p, mag, win, stream);
-      case 7: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 16>(p, mag, win, stream);
+      case 7: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64 + 128>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
       case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, 2>(p, mag, win, stream);
       case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 32>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
-      case 13: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4>(p, mag, win, stream);
+      case 13: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }
