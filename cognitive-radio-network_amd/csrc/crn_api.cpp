@@ -213,7 +213,8 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
   if (epochs_per_block) *epochs_per_block = epb;
   if (name && name_len > 0) {
     int nbuf = 1, pf = 0, nt = 0, tl = 0, pk = 0;
-    crn::sense_variant(h->cfg.fft_len, h->variant, &nbuf, &pf, &nt, &tl, &pk);
+    crn::sense_variant(h->cfg.fft_len, h->cfg.mode == CRN_MODE_REF_MAG || h->cfg.window != CRN_WINDOW_RECT ? -1 : h->variant,
+                       &nbuf, &pf, &nt, &tl, &pk);
     std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d>",
                   h->cfg.fft_len / 256, nbuf, pf, nt, tl, pk,
                   h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT);

@@ -865,10 +865,10 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 }
 
 // Default configuration of every size: all mode / window / short-frame combinations.
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = 4 + 32>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
-#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, 4 + 32>>(p, stream)
+#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
   if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
   if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
   if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
@@ -951,7 +951,11 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 int sense_num_variants() { return kNumVariants; }
 
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) {
-  if (variant <= 0 || variant > kNumVariants || fft_len != 4096) variant = kDefaultVariant;
+  if (variant < 0 || fft_len != 4096) {  // launch_default: every size / mode other than the 4096-pt plain path
+    *nbuf = 1; *prefetch = 1; *nt = 1; *tw2lds = 0; *pk = 1;
+    return;
+  }
+  if (variant == 0 || variant > kNumVariants) variant = kDefaultVariant;
   *nbuf = kVariants[variant].nbuf;
   *prefetch = kVariants[variant].prefetch;
   *nt = kVariants[variant].nt;
