@@ -1,5 +1,6 @@
 // cognitive_engine.hpp — the CRTS plugin base class, as the reference declares it
-// (reference: include/cognitive_engine.hpp:21-45, src/cognitive_engine.cpp:4-6).
+// (reference: include/cognitive_engine.hpp:21-45; its three member bodies are empty,
+// src/cognitive_engine.cpp:4-6, and live in engine_harness.cpp here).
 //
 // Engines are constructed by ExtensibleCognitiveRadio::set_ce as
 //   new CE_X(int argc, char **argv, ExtensibleCognitiveRadio *ecr)

@@ -13,6 +13,15 @@
 
 #include "CE_Predictive_Node_GPU.hpp"
 
+// The plugin base class has three empty members (reference: src/cognitive_engine.cpp:4-6).  The
+// harness provides them unless it is linked with the reference's own object code
+// (engine_harness_refbase, -DCRN_USE_REFERENCE_BASE).
+#ifndef CRN_USE_REFERENCE_BASE
+CognitiveEngine::CognitiveEngine() : ECR(NULL) {}
+CognitiveEngine::~CognitiveEngine() {}
+void CognitiveEngine::execute() { /* engines override this */ }
+#endif
+
 int main(int argc, char **argv) {
   if (argc < 3) {
     fprintf(stderr, "usage: %s iq.bin samples_per_packet [ce args]\n", argv[0]);
