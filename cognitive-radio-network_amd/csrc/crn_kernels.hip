@@ -365,6 +365,21 @@ CRN_DEV void lds_read16_b64(cx (&u)[16], const cx *base) {
 }
 #undef CRN_RD
 
+// Eight ds_read_b64 + wait as one block (pass-2 twiddles from the LDS table, two blocks per frame
+// instead of the eight dependent read-wait-multiply round trips the compiler schedules).
+template <int STRIDE_BYTES>
+CRN_DEV void lds_read8_b64(cx (&w)[8], const cx *base) {
+  const unsigned addr = (unsigned)(size_t)base;
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
+      "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
+      "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+      : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])
+      : "v"(addr), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
+        "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES)
+      : "memory");
+}
+
 template <class C>
 CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   const cx *row = buf + c.a * Geo<C::R3>::ROW;
@@ -380,6 +395,16 @@ template <class C, class Hook = NoHook>
 CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
   dft16<C::PK>(u, v, hook);
+  if constexpr (C::TW2LDS && (C::OPT & 32) != 0) {
+    cx w[8];
+    lds_read8_b64<C::R3 * 8>(w, c.tw2_lds + 1 * C::R3 + c.m_lo);  // rows 1..8
+#pragma unroll
+    for (int i = 1; i <= 8; i++) v[i] = m::mul(v[i], w[i - 1]);
+    lds_read8_b64<C::R3 * 8>(w, c.tw2_lds + 8 * C::R3 + c.m_lo);  // rows 8..15
+#pragma unroll
+    for (int i = 9; i < 16; i++) v[i] = m::mul(v[i], w[i - 8]);
+    return;
+  }
 #pragma unroll
   for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], C::TW2LDS ? c.tw2_lds[i * C::R3 + c.m_lo] : c.tw2[i]);
 }
