@@ -409,3 +409,46 @@ def test_blackman_harris_monitor_mode(built):
     n_epochs = 7
     iq, _ = signals.make_epochs(cfg, n_epochs, seed=1024)
     check_against_oracle(cfg, iq, n_epochs)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_configurations(built, seed):
+    """Random size / K / packet length / band table / mode / decision rule against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([512, 1024, 2048, 4096]))
+    mode = int(rng.integers(0, 2))
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    cfg.mode = mode
+    cfg.frames_per_epoch = int(rng.integers(1, 13))
+    cfg.window = int(rng.choice([cs.WINDOW_RECT, cs.WINDOW_HANN, cs.WINDOW_BLACKMAN_HARRIS]))
+    L = n if (cfg.window != cs.WINDOW_RECT or rng.random() < 0.5) else int(rng.integers(1, n + 1))
+    nb = int(rng.integers(1, 12))
+    edges = np.sort(rng.choice(np.arange(1, n), size=2 * nb, replace=False))
+    cfg.n_bands, cfg.n_segs = nb, nb
+    for b in range(nb):
+        cfg.segs[b].lo, cfg.segs[b].hi, cfg.segs[b].band = int(edges[2 * b]), int(edges[2 * b + 1]), b
+    cfg.decide, cfg.ref_band = cs.DECIDE_THRESHOLD, -1
+    n_epochs = int(rng.integers(1, 20))
+    spe = cs.samples_per_epoch(cfg, L)
+    iq = rng.normal(0, 1e-3, n_epochs * spe * 2).astype(np.float32)
+    # a tone in the first band of some epochs so the thresholds see both outcomes
+    t = np.arange(spe)
+    kbin = (cfg.segs[0].lo + cfg.segs[0].hi) // 2
+    for e in range(0, n_epochs, 2):
+        tone = 0.02 * np.exp(2j * np.pi * kbin * (t % L) / n)
+        seg = iq[2 * e * spe:2 * (e + 1) * spe].view(np.complex64)
+        seg += tone.astype(np.complex64)
+    ref = orc.run(cfg, iq, n_epochs, L=L)
+    thr = np.median(ref["features"], axis=0)
+    for b in range(nb):
+        cfg.thresh[b] = float(3.0 * thr[b])
+    s = cs.Sensor(cfg)
+    got = s.run_host(iq, n_epochs, L=L, want_spectrum=True)
+    s.close()
+    want = orc.run(cfg, iq, n_epochs, L=L, want_spectrum=True)
+    truth = signals.spectrum_f64(cfg, iq, n_epochs, L=L)
+    floor = FLOOR if cfg.frames_per_epoch >= 4 else 1e-1
+    assert per_bin_err(got["spectrum"], truth, floor) < 2.0 * per_bin_err(want["spectrum"], truth, floor) + 2e-6
+    assert np.allclose(got["features"], want["features"], rtol=2e-5, atol=0)
+    margin = np.abs(want["features"] / np.array(cfg.thresh[:nb], np.float32)[None, :] - 1) > 1e-4
+    assert np.array_equal(got["occupancy"][margin], want["occupancy"][margin])
