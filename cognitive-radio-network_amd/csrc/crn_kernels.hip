@@ -355,8 +355,8 @@ CRN_DEV void lds_read16_b64(cx (&u)[16], const cx *base) {
       "ds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
       "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\t"
       "ds_read_b64 %15, %16 offset:%32\n\ts_waitcnt lgkmcnt(0)"
-      : "=v"(u[0]), "=v"(u[1]), "=v"(u[2]), "=v"(u[3]), "=v"(u[4]), "=v"(u[5]), "=v"(u[6]), "=v"(u[7]), "=v"(u[8]),
-        "=v"(u[9]), "=v"(u[10]), "=v"(u[11]), "=v"(u[12]), "=v"(u[13]), "=v"(u[14]), "=v"(u[15])
+      : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]), "=&v"(u[8]),
+        "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
       : "v"(addr), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
         "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES),
         "n"(8 * STRIDE_BYTES), "n"(9 * STRIDE_BYTES), "n"(10 * STRIDE_BYTES), "n"(11 * STRIDE_BYTES),
@@ -365,6 +365,7 @@ CRN_DEV void lds_read16_b64(cx (&u)[16], const cx *base) {
 }
 #undef CRN_RD
 
+// (Outputs are early-clobber: the address register must survive until the last read has issued.)
 // Eight ds_read_b64 + wait as one block (pass-2 twiddles from the LDS table, two blocks per frame
 // instead of the eight dependent read-wait-multiply round trips the compiler schedules).
 template <int STRIDE_BYTES>
@@ -374,7 +375,7 @@ CRN_DEV void lds_read8_b64(cx (&w)[8], const cx *base) {
       "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
       "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
       "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
-      : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
       : "v"(addr), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
         "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES)
       : "memory");
