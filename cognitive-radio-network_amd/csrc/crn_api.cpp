@@ -30,6 +30,7 @@ int fail(int code, const std::string &msg) {
 struct crn_handle {
   crn_cfg cfg;
   int variant = 0;
+  unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
   // one device slab holding every table
   void *d_tables = nullptr;
   const float2 *d_tw1 = nullptr, *d_tw2 = nullptr;
@@ -128,6 +129,11 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
         for (int k = cfg->segs[s].lo; k < cfg->segs[s].hi; k++) bins.push_back(k);
       }
   }
+  if (N == 4096) {
+    h->row_mask = 0;
+    for (int sgi = 0; sgi < cfg->n_segs; sgi++)
+      for (int k = cfg->segs[sgi].lo; k < cfg->segs[sgi].hi; k++) h->row_mask |= 1u << (k >> 8);
+  }
   seg_begin[cfg->n_bands] = (int)seg_lo.size();
   bins_begin[cfg->n_bands] = (int)bins.size();
   if (bins.empty()) bins.push_back(0);
@@ -215,9 +221,12 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
     int nbuf = 1, pf = 0, nt = 0, tl = 0, pk = 0;
     crn::sense_variant(h->cfg.fft_len, h->cfg.mode == CRN_MODE_REF_MAG || h->cfg.window != CRN_WINDOW_RECT ? -1 : h->variant,
                        &nbuf, &pf, &nt, &tl, &pk);
-    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d>",
+    const bool plain4096 = h->cfg.fft_len == 4096 && h->cfg.mode != CRN_MODE_REF_MAG && h->cfg.window == CRN_WINDOW_RECT;
+    const bool pruned = plain4096 && (h->variant == 0 || h->variant == 13) && (h->row_mask & ~0x8267u) == 0;
+    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d%s>",
                   h->cfg.fft_len / 256, nbuf, pf, nt, tl, pk,
-                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT);
+                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT,
+                  pruned ? ",PASS3_ROWS=0x8267(reference channel plan; full rows when a spectrum is requested)" : "");
   }
   return CRN_OK;
 }
@@ -270,6 +279,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.n_bands = c.n_bands;
   p.decide = c.decide;
   p.ref_band = c.ref_band;
+  p.row_mask = h->row_mask;
   p.features = d_out->features;
   p.ann_out = c.decide == CRN_DECIDE_ANN ? d_out->ann_out : nullptr;
   p.decision = d_out->decision;

@@ -32,6 +32,7 @@ struct SenseParams {
   int n_bands;
   int decide;
   int ref_band;
+  unsigned row_mask;       // N = 4096: bit d set when some band touches bins [256 d, 256 d + 256)
   // outputs (device, nullable)
   float *features;
   double *ann_out;

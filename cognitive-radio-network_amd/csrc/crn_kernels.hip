@@ -161,6 +161,47 @@ CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook())
     for (int a1 = 0; a1 < 4; a1++) out[a0 + 4 * a1] = y[a1 + 4 * a0];
 }
 
+// The reference hard-codes its channel plan (bins 0-15 + 496-510, 55-84, 189-221, 300-309 of 512:
+// CE_Predictive_Node.cpp:173-191).  At N = 4096 those bands touch 7 of the 16 blocks of 256 bins, and
+// the last radix-4 level of pass 3 produces exactly one block per output: row d = bins
+// [256 d, 256 d + 256).  For band tables inside these rows, and when no per-bin spectrum is asked
+// for, pass 3 forms and accumulates only the needed outputs (bit-identical for those bins).
+static constexpr unsigned kRefPlanRows = 0x8267u;  // rows {0, 1, 2, 5, 6, 9, 15}
+
+// DFT16 whose last level only forms the outputs named in MASK (bit d = X[d] needed).
+template <bool PK, unsigned MASK>
+CRN_DEV void dft16_pruned(const cx (&in)[16], cx (&out)[16]) {
+  using m = M<PK>;
+  cx y[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = in[i];
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0++) dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+  const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
+  const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
+  y[1 + 4 * 1] = m::mul_c(y[1 + 4 * 1], w1);
+  y[1 + 4 * 2] = m::mul_c(y[1 + 4 * 2], w2);
+  y[1 + 4 * 3] = m::mul_c(y[1 + 4 * 3], w3);
+  y[2 + 4 * 1] = m::mul_c(y[2 + 4 * 1], w2);
+  y[2 + 4 * 3] = m::mul_c(y[2 + 4 * 3], w6);
+  y[3 + 4 * 1] = m::mul_c(y[3 + 4 * 1], w3);
+  y[3 + 4 * 2] = m::mul_c(y[3 + 4 * 2], w6);
+  y[3 + 4 * 3] = m::mul_c(y[3 + 4 * 3], w9);
+#pragma unroll
+  for (int a0 = 0; a0 < 4; a0++) {
+    constexpr unsigned M0 = MASK;
+    const bool n0 = (M0 >> (a0 + 0)) & 1, n1 = (M0 >> (a0 + 4)) & 1, n2 = (M0 >> (a0 + 8)) & 1, n3 = (M0 >> (a0 + 12)) & 1;
+    const cx b0 = y[4 * a0], b1 = y[4 * a0 + 1], b2 = y[4 * a0 + 2], b3 = y[4 * a0 + 3];
+    cx s02 = b0, d02 = b0, s13 = b1, d13 = b1;
+    if (n0 || n2) { s02 = a0 == 2 ? m::add_mj(b0, b2) : m::add(b0, b2); s13 = m::add(b1, b3); }
+    if (n1 || n3) { d02 = a0 == 2 ? m::sub_mj(b0, b2) : m::sub(b0, b2); d13 = m::sub(b1, b3); }
+    if (n0) out[a0 + 0] = m::add(s02, s13);
+    if (n1) out[a0 + 4] = m::add_mj(d02, d13);
+    if (n2) out[a0 + 8] = m::sub(s02, s13);
+    if (n3) out[a0 + 12] = m::sub_mj(d02, d13);
+  }
+}
+
 // 8-point forward DFT as 2 x 4.
 template <bool PK>
 CRN_DEV void dft8(const cx (&in)[8], cx (&out)[8]) {
@@ -508,6 +549,16 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
     ph_x2_write<C>(v, buf, c);
     wave_sync();
     ph_x2_read<C>(u, buf, c);
+    if constexpr ((C::OPT & 256) != 0 && C::R3 == 16 && !C::MAG) {
+      constexpr unsigned MASK = kRefPlanRows;
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = cx{0.f, 0.f};
+      dft16_pruned<C::PK, MASK>(u, v);
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if ((MASK >> i) & 1) c.acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, c.acc[i]));
+      return;
+    }
     ph_pass3_acc<C>(u, c);
     return;
   }
@@ -914,7 +965,7 @@ struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
 static constexpr VariantDesc kVariants[] = {
     /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
     /* 1 */ {1, 0, 1, 1, 4, 0, 1},
-    /* 2 */ {1, 1, 1, 0, 3, 0, 1},  // = 8, prefetch loads pinned ahead of the compute
+    /* 2 */ {1, 1, 1, 1, 4, 0, 1},  // default without the pass-3 row pruning
     /* 3 */ {1, 1, 1, 1, 3, 0, 1},
     /* 4 */ {2, 1, 1, 0, 2, 0, 1},
     /* 5 */ {1, 0, 1, 1, 4, 0, 0},
@@ -925,7 +976,7 @@ static constexpr VariantDesc kVariants[] = {
     /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // = 8 + prefetch loads spread through the butterflies + ds_read_b64 blocks
     /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
     /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
-    /* 13 */ {1, 1, 1, 1, 4, 0, 1},  // as 7 without the phase fences
+    /* 13 */ {1, 1, 1, 1, 4, 0, 1},  // default: 4 workgroups/CU, compressed tw1, tw2 from LDS, row pruning when it applies
     /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: VALU only (no reload, no LDS exchange)
     /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only at the default occupancy
 };
@@ -944,7 +995,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 1, true, true, false, 3, 0, true, 1>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
@@ -955,7 +1006,11 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 32>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
-      case 13: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
+      case 13:
+        // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
+        if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64 + 256>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }

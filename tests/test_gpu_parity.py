@@ -452,3 +452,31 @@ def test_randomised_configurations(built, seed):
     assert np.allclose(got["features"], want["features"], rtol=2e-5, atol=0)
     margin = np.abs(want["features"] / np.array(cfg.thresh[:nb], np.float32)[None, :] - 1) > 1e-4
     assert np.array_equal(got["occupancy"][margin], want["occupancy"][margin])
+
+
+def test_row_pruned_fast_path_matches_oracle(built):
+    """N = 4096 with the reference channel plan and no spectrum output runs the kernel whose last
+    radix-4 level only forms the 7 blocks of 256 bins the bands touch; a band outside those rows,
+    or a spectrum request, must fall back to the full kernel.  All three against the oracle."""
+    n_epochs = 33
+    cfg = cs.cfg_energy_scaled(4096, 4.0)
+    iq, picks = signals.make_epochs(cfg, n_epochs, seed=4096)
+    want = orc.run(cfg, iq, n_epochs)
+    s = cs.Sensor(cfg)
+    fast = s.run_host(iq, n_epochs, want_spectrum=False)
+    full = s.run_host(iq, n_epochs, want_spectrum=True)
+    s.close()
+    for got in (fast, full):
+        assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
+        assert np.array_equal(got["occupancy"], want["occupancy"])
+    assert np.array_equal(fast["features"], full["features"])  # same arithmetic for the bins that count
+    # a band in row 12 (bins 3072..3327) is outside the reference plan's rows
+    other = cs.cfg_energy_scaled(4096, 4.0)
+    other.segs[3].lo, other.segs[3].hi = 3100, 3300
+    iq2, _ = signals.make_epochs(other, n_epochs, seed=4097)
+    s = cs.Sensor(other)
+    got = s.run_host(iq2, n_epochs, want_spectrum=False)
+    s.close()
+    want2 = orc.run(other, iq2, n_epochs)
+    assert np.allclose(got["features"], want2["features"], rtol=1e-5, atol=0)
+    assert np.array_equal(got["occupancy"], want2["occupancy"])
