@@ -300,11 +300,20 @@ CRN_DEV void wave_sync() {
 //   FULL     every frame brings all N samples (L == N): no zero-padding mask
 //   PK       packed-f32 butterflies (see M<PK>)
 // ---------------------------------------------------------------------------------------------
+// OPT flags
+enum : int {
+  kPair = 2,     // two frames per wave in flight (needs NBUF == 2)
+  kSpread = 4,   // next frame's loads issued from inside passes 1 and 2, one per radix-4 group
+  kLdsBlk = 32,  // LDS reads as hand-written ds_read_b64 blocks (no ds_read2_b64 merging)
+  kTw1C = 64,    // pass-1 twiddles stored compressed (9 instead of 15 complex values)
+  kFence = 128,  // sched_barrier after pass 1
+  kRows = 256,   // pass 3 limited to the reference channel plan's output rows
+};
+
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
           bool FULL_, bool PK_, int OPT_ = 0>
 struct Cfg {
-  static constexpr int OPT = OPT_;  // bit 0: pin prefetch loads ahead of the compute; bit 1: frame pairs;
-                                    // bit 2: prefetch loads spread through the butterfly stream
+  static constexpr int OPT = OPT_;  // kPair | kSpread | kLdsBlk | kTw1C | kFence | kRows
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
@@ -331,26 +340,17 @@ struct SpreadLoads {
   cx (&nx)[16];
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned voff, soff;
-  int pass;   // 0..2: which of the frame's three DFT16s this hook sits in
-  int plan;   // how the 16 loads are spread over the hook points
-  __device__ __forceinline__ void one(int idx) const {
+  int pass;   // 0 or 1: which of the frame's first two DFT16s this hook sits in
+  bool half;  // Welch: only 8 loads (one half-frame), all in pass 1
+  __device__ __forceinline__ void operator()(int k) const {
+    if (pass > 1 || (half && pass != 0)) return;
+    const int idx = pass * 8 + k;
     __builtin_amdgcn_sched_barrier(0);
     nx[idx] = ld_iq<NT>(rsrc, voff, soff + (unsigned)(Geo<R3>::T * idx * 8));
     __builtin_amdgcn_sched_barrier(0);
   }
-  __device__ __forceinline__ void operator()(int k) const {
-    if (plan == 0) {         // 8 in pass 1, 8 in pass 2, one per radix-4 group
-      if (pass < 2) one(pass * 8 + k);
-    } else if (plan == 1) {  // all 16 in pass 1, two per radix-4 group
-      if (pass == 0) { one(2 * k); one(2 * k + 1); }
-    } else if (plan == 2) {  // 12 in pass 1 (3 per two groups), 4 in pass 2
-      if (pass == 0) { one(k + (k >> 1)); if (k & 1) one(k + (k >> 1) + 1); }
-      else if (pass == 1 && (k & 1)) one(12 + (k >> 1));
-    } else {                 // half a frame (Welch): 8 loads, one per radix-4 group of pass 1
-      if (pass == 0) one(k);
-    }
-  }
 };
+
 
 
 // ---- phases of one frame; `u` holds x[t + T r] on entry -------------------------------------
@@ -364,7 +364,7 @@ CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook
     for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
   }
   dft16<C::PK>(u, v, hook);
-  if constexpr ((C::OPT & 64) != 0) {
+  if constexpr ((C::OPT & kTw1C) != 0) {
     // compressed table: tw1[1..8] = W^{t i}, tw1[0] = W^{16 t}; W^{t (16-i)} = W^{16 t} conj(W^{t i})
 #pragma unroll
     for (int i = 1; i <= 8; i++) v[i] = m::mul(v[i], c.tw1[i]);
@@ -374,7 +374,7 @@ CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook
 #pragma unroll
     for (int i = 1; i < 16; i++) v[i] = m::mul(v[i], c.tw1[i]);
   }
-  if constexpr ((C::OPT & 128) != 0) __builtin_amdgcn_sched_barrier(0);
+  if constexpr ((C::OPT & kFence) != 0) __builtin_amdgcn_sched_barrier(0);
 }
 // exchange 1, layout [a][t] with rows of T + R3 complex
 template <class C>
@@ -425,7 +425,7 @@ CRN_DEV void lds_read8_b64(cx (&w)[8], const cx *base) {
 template <class C>
 CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   const cx *row = buf + c.a * Geo<C::R3>::ROW;
-  if constexpr ((C::OPT & 32) != 0) {
+  if constexpr ((C::OPT & kLdsBlk) != 0) {
     lds_read16_b64<C::R3 * 8>(u, row + c.m_lo);
     return;
   }
@@ -437,7 +437,7 @@ template <class C, class Hook = NoHook>
 CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
   dft16<C::PK>(u, v, hook);
-  if constexpr (C::TW2LDS && (C::OPT & 32) != 0) {
+  if constexpr (C::TW2LDS && (C::OPT & kLdsBlk) != 0) {
     cx w[8];
     lds_read8_b64<C::R3 * 8>(w, c.tw2_lds + 1 * C::R3 + c.m_lo);  // rows 1..8
 #pragma unroll
@@ -462,7 +462,7 @@ template <class C>
 CRN_DEV void ph_x2_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   constexpr int R3 = C::R3, J = Geo<R3>::J;
   const cx *row = buf + c.a * Geo<R3>::ROW;
-  if constexpr ((C::OPT & 32) != 0 && R3 == 16) {
+  if constexpr ((C::OPT & kLdsBlk) != 0 && R3 == 16) {
     lds_read16_b64<8>(u, row + 17 * c.m_lo);
     return;
   }
@@ -527,7 +527,7 @@ CRN_DEV void group_sync() {
 
 // One frame: three register passes + two LDS exchanges + per-bin accumulate.  `u` is clobbered.
 // With SPREAD the next frame (`nx`, at `soff_next`) is fetched from inside passes 1 and 2.
-template <class C, bool SPREAD = false, int PLAN_ = -1>
+template <class C, bool SPREAD = false, bool HALF = false>
 CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nullptr,
                            __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), unsigned voff = 0,
                            unsigned soff_next = 0) {
@@ -537,8 +537,7 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
   cx v[16];
   if constexpr (SPREAD) {
     static_assert(C::ABL == 0, "ablations use the plain path");
-    constexpr int PLAN = PLAN_ >= 0 ? PLAN_ : (C::OPT >> 3) & 3;
-    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, PLAN}, h2{*nx, rsrc, voff, soff_next, 1, PLAN};
+    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, HALF}, h2{*nx, rsrc, voff, soff_next, 1, HALF};
     ph_pass1<C>(u, v, c, h1);
     if constexpr (G::XWAVE && C::NBUF == 1) __syncthreads();
     ph_x1_write<C>(v, buf, c);
@@ -549,7 +548,7 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
     ph_x2_write<C>(v, buf, c);
     wave_sync();
     ph_x2_read<C>(u, buf, c);
-    if constexpr ((C::OPT & 256) != 0 && C::R3 == 16 && !C::MAG) {
+    if constexpr ((C::OPT & kRows) != 0 && C::R3 == 16 && !C::MAG) {
       constexpr unsigned MASK = kRefPlanRows;
 #pragma unroll
       for (int i = 0; i < 16; i++) v[i] = cx{0.f, 0.f};
@@ -796,8 +795,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 
   // frame-invariant twiddles, kept in registers across frames and epochs
 #pragma unroll
-  for (int i = 1; i < ((C::OPT & 64) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
-  if constexpr ((C::OPT & 64) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
+  for (int i = 1; i < ((C::OPT & kTw1C) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  if constexpr ((C::OPT & kTw1C) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
     __syncthreads();
@@ -847,7 +846,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
             ub[8 + r] = h1[r];
           }
           // H(f+2) is fetched from inside frame f's first pass, one load per radix-4 group
-          frame_compute<C, true, 3>(ub, c, f, &hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
+          frame_compute<C, true, true>(ub, c, f, &hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             h0[r] = h1[r];
@@ -858,7 +857,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         return;
       }
     }
-    if constexpr ((C::OPT & 2) != 0 && C::ABL == 0 && C::NBUF == 2) {
+    if constexpr ((C::OPT & kPair) != 0 && C::ABL == 0 && C::NBUF == 2) {
       // Frame pairs, two pairs per iteration in ping-pong: (ua, ub) and (uc, ud).
       cx uc[16], ud[16];
       load_frame<R3, NT>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
@@ -886,7 +885,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
       return;
     }
-    if constexpr ((C::OPT & 4) != 0 && C::ABL == 0 && C::PREFETCH) {
+    if constexpr ((C::OPT & kSpread) != 0 && C::ABL == 0 && C::PREFETCH) {
       // Ping-pong as below, but frame f+1's loads are issued from inside frame f's butterflies.
       int f = 0;
       for (; f + 1 < K; f += 2) {
@@ -904,10 +903,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       int f = 0;
       for (; f + 1 < K; f += 2) {
         load_frame<R3, NT>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
-        if constexpr ((C::OPT & 1) != 0) __builtin_amdgcn_sched_barrier(0);
         frame_step<C>(ua, c, f, u0);
         load_frame<R3, NT>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
-        if constexpr ((C::OPT & 1) != 0) __builtin_amdgcn_sched_barrier(0);
         frame_step<C>(ub, c, f + 1, u0);
       }
       if (f < K) frame_step<C>(ua, c, f, u0);
@@ -942,7 +939,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 }
 
 // Default configuration of every size: all mode / window / short-frame combinations.
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = 4 + 32>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
@@ -964,21 +961,21 @@ static hipError_t launch_rn(const SenseParams &p, bool, bool, hipStream_t stream
 struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
 static constexpr VariantDesc kVariants[] = {
     /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
-    /* 1 */ {1, 0, 1, 1, 4, 0, 1},
-    /* 2 */ {1, 1, 1, 1, 4, 0, 1},  // default without the pass-3 row pruning
-    /* 3 */ {1, 1, 1, 1, 3, 0, 1},
-    /* 4 */ {2, 1, 1, 0, 2, 0, 1},
-    /* 5 */ {1, 0, 1, 1, 4, 0, 0},
-    /* 6 */ {2, 1, 1, 1, 2, 0, 1},  // frame pairs (two frames per wave in flight), tw2 in LDS
-    /* 7 */ {1, 1, 1, 1, 4, 0, 1},  // 4 workgroups per CU: compressed tw1, tw2 in LDS, spread prefetch
-    /* 8 */ {1, 1, 1, 0, 3, 0, 1},
-    /* 9 */ {2, 1, 1, 0, 2, 0, 1},  // frame pairs, tw2 in registers
-    /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // = 8 + prefetch loads spread through the butterflies + ds_read_b64 blocks
+    /* 1 */ {1, 0, 1, 1, 4, 0, 1},   // 4 workgroups/CU, no explicit prefetch
+    /* 2 */ {1, 1, 1, 1, 4, 0, 1},   // the default without the pass-3 row pruning
+    /* 3 */ {1, 1, 1, 1, 3, 0, 1},   // 3 workgroups/CU, tw2 from LDS, compiler-placed loads and LDS reads
+    /* 4 */ {2, 1, 1, 0, 2, 0, 1},   // 2 workgroups/CU, two LDS buffers (one barrier per frame)
+    /* 5 */ {1, 0, 1, 1, 4, 0, 0},   // as 1 with scalar (unpacked) butterflies
+    /* 6 */ {2, 1, 1, 1, 2, 0, 1},   // frame pairs (two frames per wave in flight), tw2 from LDS
+    /* 7 */ {1, 1, 1, 1, 4, 0, 1},   // as 2 with a scheduling fence after pass 1
+    /* 8 */ {1, 1, 1, 0, 3, 0, 1},   // 3 workgroups/CU, all twiddles in registers, compiler-placed loads
+    /* 9 */ {2, 1, 1, 0, 2, 0, 1},   // frame pairs, tw2 in registers
+    /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // 8 + spread prefetch + ds_read_b64 blocks (what the other sizes run)
     /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
-    /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only
+    /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only, 2 workgroups/CU
     /* 13 */ {1, 1, 1, 1, 4, 0, 1},  // default: 4 workgroups/CU, compressed tw1, tw2 from LDS, row pruning when it applies
-    /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: VALU only (no reload, no LDS exchange)
-    /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only at the default occupancy
+    /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: butterflies only (no reload, no LDS exchange)
+    /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only, 3 workgroups/CU
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -995,22 +992,22 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C>(p, mag, win, stream);
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
-      case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, 2>(p, mag, win, stream);
-      case 7: return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64 + 128>(p, mag, win, stream);
+      case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, kPair>(p, mag, win, stream);
+      case 7: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kFence>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
-      case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, 2>(p, mag, win, stream);
-      case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, 4 + 32>(p, mag, win, stream);
+      case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, kPair>(p, mag, win, stream);
+      case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
       case 13:
         // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
         if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64 + 256>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, 4 + 32 + 64>(p, mag, win, stream);
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }
