@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Soak: many random configurations through the HIP path against the oracle (not part of the
+test suite; used to hunt rare codegen / aliasing bugs with spare GPU minutes)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd"), os.path.join(ROOT, "tests")]
+import crnsense as cs, oracle_py as orc, signals
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+bad = 0
+for seed in range(n_seeds):
+    rng = np.random.default_rng(50000 + seed)
+    n = int(rng.choice([512, 1024, 2048, 4096]))
+    ref_plan = rng.random() < 0.35
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    cfg.mode = int(rng.integers(0, 2))
+    cfg.frames_per_epoch = int(rng.integers(1, 14))
+    cfg.window = int(rng.choice([0, 0, 1, 2]))
+    L = n if (cfg.window != 0 or rng.random() < 0.6) else int(rng.integers(1, n + 1))
+    if not ref_plan:
+        nb = int(rng.integers(1, 20))
+        edges = np.sort(rng.choice(np.arange(1, n), size=2 * nb, replace=False))
+        cfg.n_bands, cfg.n_segs, cfg.ref_band = nb, nb, -1
+        for b in range(nb):
+            cfg.segs[b].lo, cfg.segs[b].hi, cfg.segs[b].band = int(edges[2 * b]), int(edges[2 * b + 1]), b
+            cfg.thresh[b] = 1e-3
+    variant = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 8, 9, 10])) if n == 4096 else 0
+    want_spec = bool(rng.random() < 0.5)
+    n_epochs = int(rng.integers(1, 40))
+    spe = cs.samples_per_epoch(cfg, L)
+    iq = rng.normal(0, 1e-3, n_epochs * spe * 2).astype(np.float32)
+    s = cs.Sensor(cfg)
+    s.set_variant(variant)
+    got = s.run_host(iq, n_epochs, L=L, want_spectrum=want_spec)
+    s.close()
+    want = orc.run(cfg, iq, n_epochs, L=L, want_spectrum=want_spec)
+    ok = np.allclose(got["features"], want["features"], rtol=3e-5, atol=0)
+    if want_spec:
+        truth = signals.spectrum_f64(cfg, iq, n_epochs, L=L)
+        fl = (1e-2 if cfg.frames_per_epoch >= 4 else 1e-1) * truth.mean(axis=1, keepdims=True)
+        eg = (np.abs(got["spectrum"] - truth) / np.maximum(truth, fl)).max()
+        eo = (np.abs(want["spectrum"] - truth) / np.maximum(truth, fl)).max()
+        ok = ok and eg < 2 * eo + 2e-6
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, dict(n=n, mode=cfg.mode, K=cfg.frames_per_epoch, win=cfg.window, L=L, variant=variant,
+                                         spec=want_spec, epochs=n_epochs, ref_plan=ref_plan))
+print(f"soak: {n_seeds} configurations, {bad} mismatches")
+sys.exit(1 if bad else 0)
