@@ -41,6 +41,8 @@ struct crn_handle {
   // scratch of crn_sense_run_host
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
+  size_t h_results_bytes = 0;
 };
 
 namespace {
@@ -190,6 +192,7 @@ int crn_sense_destroy(crn_handle *h) {
   if (!h) return CRN_OK;
   (void)hipSetDevice(h->cfg.device);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (h->h_results) (void)hipHostFree(h->h_results);
   if (h->d_tables) (void)hipFree(h->d_tables);
   delete h;
   return CRN_OK;
@@ -329,12 +332,25 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   hipStream_t s = nullptr;
   HIP_TRY(hipMemcpyAsync(d_iq, iq, n_samples * 8, hipMemcpyHostToDevice, s));
   if (int rc = crn_sense_run_device(h, d_iq, n_epochs, samples_per_frame, epoch_stride, &d, s)) return rc;
-  if (out->features) HIP_TRY(hipMemcpyAsync(out->features, d.features, (size_t)n_epochs * c.n_bands * sizeof(float), hipMemcpyDeviceToHost, s));
-  if (out->ann_out && c.decide == CRN_DECIDE_ANN) HIP_TRY(hipMemcpyAsync(out->ann_out, d.ann_out, (size_t)n_epochs * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (out->decision) HIP_TRY(hipMemcpyAsync(out->decision, d.decision, (size_t)n_epochs * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (out->occupancy) HIP_TRY(hipMemcpyAsync(out->occupancy, d.occupancy, (size_t)n_epochs * c.n_bands, hipMemcpyDeviceToHost, s));
+  // features | ann_out | decision | occupancy sit back to back in the scratch slab: one D2H into
+  // pinned staging, then scatter on the host (a decision costs one upload, one launch, one download)
+  const size_t res_bytes = b_feat + b_ann + b_dec + b_occ;
+  if (res_bytes > h->h_results_bytes) {
+    if (h->h_results) (void)hipHostFree(h->h_results);
+    h->h_results = nullptr;
+    h->h_results_bytes = 0;
+    hipError_t e = hipHostMalloc(&h->h_results, res_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return crn::fail(CRN_ERR_NOMEM, std::string("hipHostMalloc(results): ") + hipGetErrorString(e));
+    h->h_results_bytes = res_bytes;
+  }
+  HIP_TRY(hipMemcpyAsync(h->h_results, b + b_iq, res_bytes, hipMemcpyDeviceToHost, s));
   if (out->spectrum) HIP_TRY(hipMemcpyAsync(out->spectrum, d.spectrum, (size_t)n_epochs * c.fft_len * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  const char *r = static_cast<const char *>(h->h_results);
+  if (out->features) std::memcpy(out->features, r, (size_t)n_epochs * c.n_bands * sizeof(float));
+  if (out->ann_out && c.decide == CRN_DECIDE_ANN) std::memcpy(out->ann_out, r + b_feat, (size_t)n_epochs * 3 * sizeof(double));
+  if (out->decision) std::memcpy(out->decision, r + b_feat + b_ann, (size_t)n_epochs * sizeof(int32_t));
+  if (out->occupancy) std::memcpy(out->occupancy, r + b_feat + b_ann + b_dec, (size_t)n_epochs * c.n_bands);
   return CRN_OK;
 }
 
