@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=0, help="decision epochs per GPU per step (0 = 8.75 GiB of IQ)")
     ap.add_argument("--mode", choices=["energy", "ref", "welch"], default="energy")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per epoch K (0 = the configuration's own, 10)")
     ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip)")
     ap.add_argument("--per-launch-events", action="store_true", help="time each launch with its own event pair")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
@@ -84,6 +85,9 @@ def main():
         cfg = cs.cfg_energy_scaled(args.fft, 4.0)
         workload = f"{args.fft}-pt FFT + energy detect x 3ch (+noise-floor band), K=10, threshold"
     cfg.device = local_rank
+    if args.frames > 0:
+        cfg.frames_per_epoch = args.frames
+        workload += f" [K={args.frames}]"
     N, K = cfg.fft_len, cfg.frames_per_epoch
     spe = cs.samples_per_epoch(cfg)
     E = args.epochs if args.epochs > 0 else (28672 * 40960) // spe   # per GPU (weak scaling)

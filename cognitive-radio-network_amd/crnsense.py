@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcrnsense.so")
+LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense.so")  # env override: A/B builds
 
 CRN_ABI_VERSION = 1
 CRN_MAX_BANDS = 80

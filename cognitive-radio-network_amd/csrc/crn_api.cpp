@@ -30,6 +30,7 @@ int fail(int code, const std::string &msg) {
 struct crn_handle {
   crn_cfg cfg;
   int variant = 0;
+  int groups_per_wg = 0;        // 0 = automatic
   unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
   // one device slab holding every table
   void *d_tables = nullptr;
@@ -207,6 +208,10 @@ int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) {
 
 int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  if (variant >= 100 && variant <= 108) {  // A/B: 100 + n = n epoch groups per workgroup (100 = automatic)
+    h->groups_per_wg = variant - 100;
+    return CRN_OK;
+  }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
   h->variant = variant;
   return CRN_OK;
@@ -257,7 +262,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
   // a workgroup addresses its window with 32-bit byte offsets
-  if ((8 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * 8 >= ((int64_t)1 << 31))
+  if ((64 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * 8 >= ((int64_t)1 << 31))
     return crn::fail(CRN_ERR_ARG, "epoch_stride too large (a workgroup window must stay below 2 GiB)");
   const crn_cfg &c = h->cfg;
   crn::SenseParams p{};
@@ -269,6 +274,15 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.frame_stride = frame_stride;
   p.L = samples_per_frame;
   p.K = c.frames_per_epoch;
+  {
+    // Several epoch groups per workgroup amortise its prologue, but keep >= ~4 rounds of workgroups
+    // over the 256 CUs x 4 slots so the hardware dispatcher can still balance the tail.
+    const int groups = 256 / (c.fft_len / 16);
+    const int64_t n_groups = (n_epochs + groups - 1) / groups;
+    int64_t epw = n_groups / 4096;
+    p.groups_per_wg = (int)(epw < 1 ? 1 : epw > 4 ? 4 : epw);
+    if (h->groups_per_wg > 0) p.groups_per_wg = h->groups_per_wg;
+  }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;
   p.window = h->d_window;

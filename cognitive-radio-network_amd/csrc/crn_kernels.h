@@ -18,6 +18,7 @@ struct SenseParams {
   int frame_stride;        // samples between frame starts inside an epoch
   int L;                   // samples taken per frame (zero-padded to N)
   int K;                   // frames per epoch
+  int groups_per_wg;       // consecutive epoch groups one workgroup streams through (>= 1)
   // tables (device, built at crn_sense_create)
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}

@@ -308,6 +308,7 @@ enum : int {
   kTw1C = 64,    // pass-1 twiddles stored compressed (9 instead of 15 complex values)
   kFence = 128,  // sched_barrier after pass 1
   kRows = 256,   // pass 3 limited to the reference channel plan's output rows
+  kMulti = 512,  // a workgroup streams through several consecutive epoch groups
   kPrioValu = 1024, // s_setprio 1 through the butterflies of passes 1 and 2 (where the prefetch loads issue)
 
 };
@@ -653,10 +654,10 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
   int t = c.t;
   asm volatile("" : "+v"(t));
   const int a = t / R3, m_lo = t % R3;
-  if constexpr (!MAG) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = __fdiv_rn(acc[i], Kf);
-  }
+  // Energy mode: the division by K is applied to the band sums (and to the per-bin values only
+  // when a spectrum is requested) — sixteen IEEE divides per thread per epoch were half a frame's
+  // worth of VALU work.  Sum-then-divide differs from the reference order (divide-then-sum) by
+  // rounding only.
   cx *gb = c.gbuf;
   asm volatile("" : "+v"(gb));
   float *spec = reinterpret_cast<float *>(gb);            // N + N/16 floats
@@ -667,6 +668,10 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
   for (int j = 0; j < J; j++)
 #pragma unroll
     for (int d = 0; d < R3; d++) {
+      // the row-pruned kernel never accumulates (or reads back) the other rows
+      if constexpr ((C::OPT & kRows) != 0 && R3 == 16 && !MAG) {
+        if (!((kRefPlanRows >> d) & 1)) continue;
+      }
       const int k = a + 16 * (m_lo * J + j) + 256 * d;
       spec[spec_phys(k)] = acc[j * R3 + d];
     }
@@ -678,7 +683,10 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
   if (p.spectrum != nullptr && active) {
     float *dst = p.spectrum + epoch * N;
 #pragma unroll
-    for (int r = 0; r < 16; r++) dst[t + T * r] = spec[spec_phys(t + T * r)];
+    for (int r = 0; r < 16; r++) {
+      const float x = spec[spec_phys(t + T * r)];
+      dst[t + T * r] = MAG ? x : __fdiv_rn(x, Kf);
+    }
   }
 
   // band sums (reference .cpp:173-191), one team of lanes per band
@@ -695,7 +703,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
       }
 #pragma unroll
       for (int off = TEAM / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, TEAM);
-      if (lane == 0) feat[b] = MAG ? s * s : s;  // .cpp:194-197
+      if (lane == 0) feat[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
     }
   }
   if constexpr (G::XWAVE) __syncthreads();
@@ -757,19 +765,20 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
         for (int b = t; b < p.n_bands; b += T) p.occupancy[epoch * p.n_bands + b] = 0;
     }
   }
-  // the exchange buffers are reused by the next epoch's first frame
-  if constexpr (G::XWAVE) __syncthreads();
-  else wave_sync();
+  // With one exchange buffer the next epoch's first frame syncs the workgroup before it writes
+  // exchange 1 (frame_compute), which is after every wave has passed this point: no barrier here.
+  if constexpr (G::XWAVE && C::NBUF == 2) __syncthreads();
+  if constexpr (!G::XWAVE) wave_sync();
 }
 
 // Buffer resource over the IQ window of epoch group `eg` (GROUPS consecutive epochs): anything
 // past the window, or past the end of the batch, reads as zero.
 template <int R3>
-CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg) {
+CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg, int span = 1) {
   using G = Geo<R3>;
   const long long first = eg * G::GROUPS * p.epoch_stride;
   long long left = (p.total_samples - first) * 8;
-  const long long window = ((long long)G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * 8;
+  const long long window = ((long long)span * G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * 8;
   if (left > window) left = window;
   if (left < 0) left = 0;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
@@ -895,8 +904,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
       return;
     }
-    if constexpr ((C::OPT & kSpread) != 0 && C::ABL == 0 && C::PREFETCH) {
-      // Ping-pong as below, but frame f+1's loads are issued from inside frame f's butterflies.
+    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) == 0 && C::ABL == 0 && C::PREFETCH) {
+      // One epoch group per workgroup; frame f+1's loads are issued from inside frame f's butterflies.
       int f = 0;
       for (; f + 1 < K; f += 2) {
         frame_compute<C, true>(ua, c, f, &ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
@@ -904,6 +913,43 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       }
       if (f < K) frame_compute<C>(ua, c, f);
       epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+      return;
+    }
+    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH) {
+      // This workgroup owns p.groups_per_wg consecutive epoch groups and treats their frames as
+      // one stream: twiddles are loaded once, and the first frame of the next epoch is already in
+      // flight while the last frame of this one is computed and closed (the per-workgroup prologue
+      // and the exposed first load cost ~6 % at one epoch per workgroup).  Two register sets in
+      // ping-pong; frame f+1's loads are issued from inside frame f's butterflies.
+      const int epw = p.groups_per_wg;
+      const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+      const long long g0 = (long long)blockIdx.x * epw;
+      const int n_local = (int)((n_groups - g0) < epw ? (n_groups - g0) : epw);
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, g0, epw);
+      const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * 8u;
+      load_frame<R3, NT>(ua, rs, voff, 0u);
+      int j = 0, f = 0;
+#define CRN_STREAM_STEP(CUR, NXT)                                                                   \
+      {                                                                                             \
+        const bool last = f + 1 == K;                                                               \
+        const int j_n = last ? j + 1 : j;                                                           \
+        const int f_n = last ? 0 : f + 1;                                                           \
+        const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
+        frame_compute<C, true>(CUR, c, f, &NXT, rs, voff, soff_n);                                   \
+        if (last) {                                                                                 \
+          const long long ep = (g0 + j) * G::GROUPS + grp;                                          \
+          epoch_close<C>(c, p, ep, ep < p.n_epochs);                                                \
+        }                                                                                           \
+        j = j_n;                                                                                    \
+        f = f_n;                                                                                    \
+      }
+      while (true) {
+        CRN_STREAM_STEP(ua, ub)
+        if (j >= n_local) break;
+        CRN_STREAM_STEP(ub, ua)
+        if (j >= n_local) break;
+      }
+#undef CRN_STREAM_STEP
       return;
     }
     if constexpr (C::PREFETCH && C::ABL < 2) {
@@ -935,7 +981,11 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 template <class C>
 static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   using G = Geo<C::R3>;
-  const unsigned grid = (unsigned)((p.n_epochs + G::GROUPS - 1) / G::GROUPS);
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
+                     !(C::WIN && p.frame_stride * 2 == G::N);
+  const int epw = multi ? p.groups_per_wg : 1;
+  const unsigned grid = (unsigned)((n_groups + epw - 1) / epw);
   const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + (C::TW2LDS ? 16 * C::R3 : 0)) * sizeof(cx);
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
@@ -949,7 +999,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 }
 
 // Default configuration of every size: all mode / window / short-frame combinations.
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
@@ -995,22 +1045,27 @@ template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || win || p.L != Geo<R3>::N)
     variant = kDefaultVariant;
+  // Windowed kernels carry 16 more registers (the window): 3 workgroups per CU, all twiddles in
+  // registers.  Everything else runs 4 per CU with the compressed pass-1 table and pass 2 from LDS.
   if constexpr (R3 != 16) {
-    return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
+    // N = 1024 (one wave per frame) runs one epoch group per workgroup: the streaming loop costs it
+    // registers (spills inside the frame loop) and loses 3 %; the other sizes gain 2.5-3 % from it.
+    if constexpr (R3 == 4) return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu>(p, mag, win, stream);
+    else return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
   } else {
     if (variant == kDefaultVariant && (mag || win || p.L != Geo<R3>::N))
       return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu>(p, mag, win, stream);
+      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
       case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, kPair>(p, mag, win, stream);
       case 7:
         if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C>(p, mag, win, stream);
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kMulti>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kMulti>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
       case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, kPair>(p, mag, win, stream);
       case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk>(p, mag, win, stream);
@@ -1019,8 +1074,8 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 13:
         // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
         if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu>(p, mag, win, stream);
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
     }
