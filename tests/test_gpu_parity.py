@@ -480,3 +480,23 @@ def test_row_pruned_fast_path_matches_oracle(built):
     want2 = orc.run(other, iq2, n_epochs)
     assert np.allclose(got["features"], want2["features"], rtol=1e-5, atol=0)
     assert np.array_equal(got["occupancy"], want2["occupancy"])
+
+
+@pytest.mark.parametrize("n,n_epochs,epw", [(512, 67, 3), (4096, 11, 4), (2048, 21, 2), (4096, 9, 8)])
+def test_streaming_workgroups_over_several_epoch_groups(built, n, n_epochs, epw):
+    """A workgroup that streams through `epw` consecutive epoch groups (prefetching across epoch
+    boundaries) with a ragged last workgroup: same results as the oracle, odd and even K."""
+    for K in (10, 3):
+        cfg = cs.cfg_energy_scaled(n, 4.0)
+        cfg.frames_per_epoch = K
+        iq, picks = signals.make_epochs(cfg, n_epochs, seed=n + epw + K)
+        s = cs.Sensor(cfg)
+        s.set_variant(100 + epw)
+        got = s.run_host(iq, n_epochs, want_spectrum=(K == 3))
+        s.close()
+        want = orc.run(cfg, iq, n_epochs, want_spectrum=(K == 3))
+        assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
+        assert np.array_equal(got["occupancy"], want["occupancy"])
+        if K == 3:
+            truth = signals.spectrum_f64(cfg, iq, n_epochs)
+            assert per_bin_err(got["spectrum"], truth, 1e-1) < PER_BIN_TOL
