@@ -37,7 +37,7 @@ struct crn_handle {
   const float2 *d_tw1 = nullptr, *d_tw2 = nullptr;
   const float *d_window = nullptr, *d_thresh = nullptr;
   const int *d_band_seg_begin = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
-  const int *d_band_bins_begin = nullptr, *d_band_bins = nullptr;
+  const int *d_band_bins_begin = nullptr, *d_band_bins = nullptr, *d_band_tab = nullptr;
   const double *d_wih = nullptr, *d_who = nullptr;
   // scratch of crn_sense_run_host
   void *d_scratch = nullptr;
@@ -141,6 +141,15 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   bins_begin[cfg->n_bands] = (int)bins.size();
   if (bins.empty()) bins.push_back(0);
 
+  // packed band table for the kernel's LDS copy (layout: crn_kernels.h)
+  std::vector<int> band_tab(512, 0);
+  for (size_t i = 0; i < seg_begin.size(); i++) band_tab[i] = seg_begin[i];
+  for (size_t i = 0; i < seg_lo.size(); i++) {
+    band_tab[96 + i] = seg_lo[i];
+    band_tab[256 + i] = seg_hi[i];
+  }
+  std::memcpy(&band_tab[416], cfg->thresh, sizeof(float) * CRN_MAX_BANDS);
+
   struct Piece { const void *src; size_t bytes; size_t off; };
   std::vector<Piece> pieces = {
       {tw1.data(), tw1.size() * sizeof(float2), 0},
@@ -154,6 +163,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
       {bins.data(), bins.size() * sizeof(int), 0},
       {cfg->ann_w_ih, sizeof(cfg->ann_w_ih), 0},
       {cfg->ann_w_ho, sizeof(cfg->ann_w_ho), 0},
+      {band_tab.data(), band_tab.size() * sizeof(int), 0},
   };
   size_t total = 0;
   for (auto &p : pieces) {
@@ -185,6 +195,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   h->d_band_bins = reinterpret_cast<const int *>(base + pieces[8].off);
   h->d_wih = reinterpret_cast<const double *>(base + pieces[9].off);
   h->d_who = reinterpret_cast<const double *>(base + pieces[10].off);
+  h->d_band_tab = reinterpret_cast<const int *>(base + pieces[11].off);
   *out = h;
   return CRN_OK;
 }
@@ -286,6 +297,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;
   p.window = h->d_window;
+  p.band_tab = h->d_band_tab;
   p.band_seg_begin = h->d_band_seg_begin;
   p.seg_lo = h->d_seg_lo;
   p.seg_hi = h->d_seg_hi;

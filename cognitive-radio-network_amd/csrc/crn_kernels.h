@@ -23,6 +23,8 @@ struct SenseParams {
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}
   const float *window;     // [N] or null
+  const int *band_tab;        // [512] packed copy of the four tables below, staged into LDS by every workgroup:
+                              //   [0,96) band_seg_begin, [96,256) seg_lo, [256,416) seg_hi, [416,496) thresh (float bits)
   const int *band_seg_begin;  // [n_bands + 1] into seg_lo/seg_hi (segments grouped by band)
   const int *seg_lo;
   const int *seg_hi;

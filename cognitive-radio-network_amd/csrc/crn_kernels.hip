@@ -330,6 +330,7 @@ struct FrameCtx {
   float win[16];
   float acc[16];
   const cx *tw2_lds;
+  const int *tab;  // LDS copy of the band table (layout: crn_kernels.h, SenseParams::band_tab)
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
   float Kf, invK;
@@ -660,6 +661,9 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
   // rounding only.
   cx *gb = c.gbuf;
   asm volatile("" : "+v"(gb));
+  const int *tab = c.tab;
+  asm volatile("" : "+v"(tab));
+  const float *thr = reinterpret_cast<const float *>(tab + 416);
   float *spec = reinterpret_cast<float *>(gb);            // N + N/16 floats
   float *feat = spec + spec_phys(N);                      // CRN_MAX_BANDS floats
   if constexpr (G::XWAVE) __syncthreads();
@@ -696,9 +700,9 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
     const int team = t / TEAM, lane = t % TEAM;
     for (int b = team; b < p.n_bands; b += TEAMS) {
       float s = 0.f;
-      const int s0 = p.band_seg_begin[b], s1 = p.band_seg_begin[b + 1];
+      const int s0 = tab[b], s1 = tab[b + 1];
       for (int sg = s0; sg < s1; sg++) {
-        const int lo = p.seg_lo[sg], hi = p.seg_hi[sg];
+        const int lo = tab[96 + sg], hi = tab[256 + sg];
         for (int k = lo + lane; k < hi; k += TEAM) s += spec[spec_phys(k)];
       }
 #pragma unroll
@@ -753,10 +757,10 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
       const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
       if (p.occupancy != nullptr)
         for (int b = t; b < p.n_bands; b += T)
-          p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > p.thresh[b] * ref);
+          p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > thr[b] * ref);
       if (t == 0 && p.decision != nullptr) {
         int cnt = 0;
-        for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > p.thresh[b] * ref) ? 1 : 0;
+        for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > thr[b] * ref) ? 1 : 0;
         p.decision[epoch] = cnt;
       }
     } else {
@@ -816,10 +820,19 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 #pragma unroll
   for (int i = 1; i < ((C::OPT & kTw1C) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
   if constexpr ((C::OPT & kTw1C) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
+  {
+    // band table -> LDS (2 KiB behind the exchange buffers and the tw2 table): the epoch close walks
+    // it, and from global memory every walk step was a dependent ~1 us vector load
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
+    tab[tid] = p.band_tab[tid];
+    tab[tid + 256] = p.band_tab[tid + 256];
+    c.tab = tab;
+  }
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
-    __syncthreads();
-  } else {
+  }
+  __syncthreads();
+  if constexpr (!C::TW2LDS) {
 #pragma unroll
     for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
   }
@@ -986,7 +999,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
                      !(C::WIN && p.frame_stride * 2 == G::N);
   const int epw = multi ? p.groups_per_wg : 1;
   const unsigned grid = (unsigned)((n_groups + epw - 1) / epw);
-  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + (C::TW2LDS ? 16 * C::R3 : 0)) * sizeof(cx);
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + 512 * sizeof(int);
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
   if (lds > 48 * 1024) {
@@ -1117,7 +1130,8 @@ void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int 
   sense_variant(fft_len, variant, &nbuf, &pf, &nt, &tl, &pk);
   *threads = 256;
   *epochs_per_block = groups;
-  *lds_bytes = (groups * nbuf * 16 * (t + r3) + (tl ? 16 * r3 : 0)) * 8;
+  (void)tl;
+  *lds_bytes = (groups * nbuf * 16 * (t + r3) + 16 * r3) * 8 + 2048;
 }
 
 // ---------------------------------------------------------------------------------------------
