@@ -330,7 +330,8 @@ struct FrameCtx {
   float win[16];
   float acc[16];
   const cx *tw2_lds;
-  const int *tab;  // LDS copy of the band table (layout: crn_kernels.h, SenseParams::band_tab)
+  int wave;           // wave index in the workgroup (SGPR)
+  unsigned lds_base;  // LDS byte offset of the dynamic segment (SGPR); the band table copy sits behind tw2
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
   float Kf, invK;
@@ -536,7 +537,6 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
                            __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), unsigned voff = 0,
                            unsigned soff_next = 0) {
   using G = Geo<C::R3>;
-  using m = M<C::PK>;
   cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
   cx v[16];
   if constexpr (SPREAD) {
@@ -641,31 +641,65 @@ CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]
 // Epoch close (reference .cpp:157-261 + the reset at :287-288): K-frame averages -> LDS in natural
 // bin order -> band sums -> features -> decision.  Resets the accumulators for the next epoch.
 // ---------------------------------------------------------------------------------------------
+// LDS address-space views for the epoch close (see epoch_close): ds_* instructions, lgkmcnt only.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
+CRN_DEV unsigned lds_offset(const void *p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
+}
+
+// Sum over a team of TEAM consecutive lanes (32 or 64), every lane gets the total: butterflies on
+// the DPP path (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) up to 16-lane rows, then the
+// four row sums come back through v_readlane.  No LDS-pipe shuffles.
+template <int CTRL>
+CRN_DEV float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int TEAM>
+CRN_DEV float team_sum(float v, int tid) {
+  static_assert(TEAM == 32 || TEAM == 64, "team is half a wave or a wave");
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  if constexpr (TEAM == 64) return (r0 + r1) + (r2 + r3);
+  else return (tid & 32) ? r2 + r3 : r0 + r1;
+}
+
 template <class C>
-CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, bool active) {
+CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_base) {
   constexpr int R3 = C::R3;
   constexpr bool MAG = C::MAG;
   using G = Geo<R3>;
   constexpr int T = G::T, N = G::N, J = G::J;
   float (&acc)[16] = c.acc;
   const float Kf = c.Kf;
-  // Re-derive the lane coordinates behind an opaque move: otherwise the compiler hoists this
-  // block's address arithmetic out of the frame loop and keeps (or spills) ~40 registers for a
-  // block that runs once per K frames.
-  int t = c.t;
-  asm volatile("" : "+v"(t));
+  // Everything this block needs is re-derived here from uniform values (SGPRs) and the hardware
+  // lane id, so that nothing but the accumulators stays live in VGPRs across the frame loop for a
+  // block that runs once per K frames: what the allocator kept for it, it spilled, and a scratch
+  // reload waits on vmcnt behind the next frame's prefetch.
+  const int tid = c.wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int t = tid % T, grp = tid / T;
+  const long long epoch = epoch_base + grp;
+  const bool active = epoch < p.n_epochs;
   const int a = t / R3, m_lo = t % R3;
   // Energy mode: the division by K is applied to the band sums (and to the per-bin values only
   // when a spectrum is requested) — sixteen IEEE divides per thread per epoch were half a frame's
   // worth of VALU work.  Sum-then-divide differs from the reference order (divide-then-sum) by
   // rounding only.
-  cx *gb = c.gbuf;
-  asm volatile("" : "+v"(gb));
-  const int *tab = c.tab;
-  asm volatile("" : "+v"(tab));
-  const float *thr = reinterpret_cast<const float *>(tab + 416);
-  float *spec = reinterpret_cast<float *>(gb);            // N + N/16 floats
-  float *feat = spec + spec_phys(N);                      // CRN_MAX_BANDS floats
+  // The opaque values are 32-bit LDS offsets, not generic pointers: through a generic pointer every
+  // access below became a FLAT instruction followed by s_waitcnt vmcnt(0), which also drained the
+  // next frame's prefetch at every epoch close.
+  const unsigned tab_off = c.lds_base + (unsigned)((G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * R3) * sizeof(cx));
+  const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * G::GROUP_CPLX * sizeof(cx));
+  const lds_i32 *tab = reinterpret_cast<const lds_i32 *>(tab_off);
+  const lds_f32 *thr = reinterpret_cast<const lds_f32 *>(tab_off + 416 * 4);
+  lds_f32 *spec = reinterpret_cast<lds_f32 *>(gb_off);    // N + N/16 floats
+  lds_f32 *feat = spec + spec_phys(N);                    // CRN_MAX_BANDS floats
   if constexpr (G::XWAVE) __syncthreads();
   else wave_sync();
 #pragma unroll
@@ -693,7 +727,9 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
     }
   }
 
-  // band sums (reference .cpp:173-191), one team of lanes per band
+  // band sums (reference .cpp:173-191), one team of lanes per band.  This stretch is pure latency
+  // (the wave has no loads in flight beyond its prefetched frame), so: table walk from LDS, four
+  // independent bin reads per trip, DPP/readlane reduction instead of ds_bpermute shuffles.
   {
     constexpr int TEAM = G::TEAM;
     constexpr int TEAMS = T / TEAM;
@@ -703,10 +739,18 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
       const int s0 = tab[b], s1 = tab[b + 1];
       for (int sg = s0; sg < s1; sg++) {
         const int lo = tab[96 + sg], hi = tab[256 + sg];
-        for (int k = lo + lane; k < hi; k += TEAM) s += spec[spec_phys(k)];
-      }
+        for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
+          float v[4];
 #pragma unroll
-      for (int off = TEAM / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, TEAM);
+          for (int i = 0; i < 4; i++) {
+            const int k = k0 + i * TEAM;
+            const float x = spec[spec_phys(k < hi ? k : lo)];
+            v[i] = k < hi ? x : 0.f;
+          }
+          s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      }
+      s = team_sum<TEAM>(s, tid);
       if (lane == 0) feat[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
     }
   }
@@ -754,14 +798,22 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch, 
           for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
       }
     } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
-      const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
-      if (p.occupancy != nullptr)
-        for (int b = t; b < p.n_bands; b += T)
-          p.occupancy[epoch * p.n_bands + b] = (uint8_t)(feat[b] > thr[b] * ref);
-      if (t == 0 && p.decision != nullptr) {
+      // the first team of the group decides: lane i takes bands i, i + TEAM, ...; the count of
+      // occupied bands is a ballot, not a serial walk
+      constexpr int TEAM = G::TEAM;
+      if (t < TEAM) {
+        const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
         int cnt = 0;
-        for (int b = 0; b < p.n_bands; b++) cnt += (feat[b] > thr[b] * ref) ? 1 : 0;
-        p.decision[epoch] = cnt;
+        for (int b0 = 0; b0 < p.n_bands; b0 += TEAM) {
+          const int b = b0 + t;
+          const bool in = b < p.n_bands;
+          const bool occ = in && feat[in ? b : 0] > thr[in ? b : 0] * ref;
+          if (in && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + b] = (uint8_t)occ;
+          unsigned long long m = __ballot(occ);
+          if constexpr (TEAM == 32) m = (m >> (tid & 32)) & 0xffffffffull;
+          cnt += __popcll(m);
+        }
+        if (t == 0 && p.decision != nullptr) p.decision[epoch] = cnt;
       }
     } else {
       if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
@@ -811,6 +863,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.m_lo = m_lo;
   c.L = p.L;
   c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
   c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
   const int K = p.K;
   c.Kf = (float)K;
@@ -826,7 +880,6 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
     tab[tid] = p.band_tab[tid];
     tab[tid + 256] = p.band_tab[tid + 256];
-    c.tab = tab;
   }
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
@@ -851,7 +904,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   [[maybe_unused]] cx u0[16];
 
   {
-    const long long epoch = (long long)blockIdx.x * G::GROUPS + grp;
+    const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
     load_frame<R3, NT>(ua, rsrc, voff, 0u);
     if constexpr (C::ABL >= 2) {
@@ -885,7 +938,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
             h1[r] = hn[r];
           }
         }
-        epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+        epoch_close<C>(c, p, epoch_base);
         return;
       }
     }
@@ -914,7 +967,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         group_sync<C>();
         frame_compute<C>(ua, c, 0);
       }
-      epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+      epoch_close<C>(c, p, epoch_base);
       return;
     }
     if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) == 0 && C::ABL == 0 && C::PREFETCH) {
@@ -925,7 +978,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         frame_compute<C, true>(ub, c, f + 1, &ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
       }
       if (f < K) frame_compute<C>(ua, c, f);
-      epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+      epoch_close<C>(c, p, epoch_base);
       return;
     }
     if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH) {
@@ -950,8 +1003,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
         frame_compute<C, true>(CUR, c, f, &NXT, rs, voff, soff_n);                                   \
         if (last) {                                                                                 \
-          const long long ep = (g0 + j) * G::GROUPS + grp;                                          \
-          epoch_close<C>(c, p, ep, ep < p.n_epochs);                                                \
+          epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                               \
         }                                                                                           \
         j = j_n;                                                                                    \
         f = f_n;                                                                                    \
@@ -984,7 +1036,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
           load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
       }
     }
-    epoch_close<C>(c, p, epoch, epoch < p.n_epochs);
+    epoch_close<C>(c, p, epoch_base);
   }
 }
 
