@@ -50,15 +50,22 @@ def main():
     ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip)")
     ap.add_argument("--per-launch-events", action="store_true", help="time each launch with its own event pair")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="dry run of the N>1 code path on one GPU: RCCL group of one rank, all-gather every step")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: everything else this process (or a library under it:
+    # RCCL prints a version banner at init) writes to fd 1 goes to stderr instead.
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import crnsense as cs
-    from sharding import gather_occupancy, shard
+    from sharding import OccupancyExchange, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -69,8 +76,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: libcrnsense has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_collective
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     if args.mode == "ref":
@@ -105,17 +116,24 @@ def main():
     occ = torch.empty(E, cfg.n_bands, dtype=torch.uint8, device=dev)
     dec = torch.empty(E, dtype=torch.int32, device=dev)
     ann = torch.empty(E, 3, dtype=torch.float64, device=dev)
-    occ_all = torch.empty(world * E, cfg.n_bands, dtype=torch.uint8, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
     sensor.synth_fill_device(iq.data_ptr(), E, spe, seed=0xC0FFEE + 1000 * rank, truth_ptr=truth.data_ptr(),
                              stream=stream)
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
+    # N > 1: the occupancy block alternates between two slots so that the all-gather of step i
+    # (side stream) overlaps the sensing kernel of step i + 1 (sharding.OccupancyExchange)
+    ex = OccupancyExchange(E, cfg.n_bands, dev) if multi else None
+    n_done = 0
 
     def step():
+        nonlocal n_done
+        if multi:
+            outs["occupancy"] = ex.local(n_done).data_ptr()
         sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
-        if world > 1:
-            gather_occupancy(occ, occ_all)
+        if multi:
+            ex.exchange(n_done)
+        n_done += 1
 
     # Clock ramp: on this part a cold process needs ~25 ms of back-to-back launches before the
     # per-launch time settles, so the W warm-up steps are topped up to at least
@@ -127,26 +145,32 @@ def main():
     span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     span[0].record()
     for i in range(args.steps):
-        if world > 1 or args.per_launch_events:
+        if multi:
+            outs["occupancy"] = ex.local(n_done).data_ptr()
+        if multi or args.per_launch_events:
             ev[i][0].record()
         sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
-        if world > 1 or args.per_launch_events:
+        if multi or args.per_launch_events:
             ev[i][1].record()
-        if world > 1:
-            gather_occupancy(occ, occ_all)
+        if multi:
+            ex.exchange(n_done)
+        n_done += 1
+    if multi:
+        ex.finish()
+        occ = ex.local_bufs[(n_done - 1) % ex.depth]
     span[1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -154,7 +178,7 @@ def main():
     # Kernel duration from events on the launch stream.  One GPU: one pair around the K back-to-back
     # launches (mean includes the ~us dispatch gap between consecutive kernels, no per-event cost).
     # Several GPUs: a pair per launch, because the all-gather sits between launches.
-    if world > 1 or args.per_launch_events:
+    if multi or args.per_launch_events:
         kern_ms = [a.elapsed_time(b) for a, b in ev]
     else:
         kern_ms = [span[0].elapsed_time(span[1]) / args.steps]
@@ -228,15 +252,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
                        "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
-                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy" if world > 1 else "")},
+                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy" if multi else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms_mean": kern_ms_mean, "kernel_ms_min": float(np.min(kern_ms)),
                          "kernel_ms_median": float(np.median(kern_ms))},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print(json.dumps(line), file=json_out, flush=True)
+    if multi:
+        # every rank must find its own block, unchanged, at its place in the gathered vector
+        if not args.no_check and not torch.equal(ex.gathered(n_done - 1)[rank * E:(rank + 1) * E], occ):
+            raise SystemExit(f"bench: rank {rank}: gathered occupancy differs from the local block")
         dist.destroy_process_group()
 
 

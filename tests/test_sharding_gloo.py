@@ -62,3 +62,50 @@ def test_two_rank_gather_equals_single_process(built):
     want = orc.run(cfg, iq, n_epochs)["occupancy"]
     assert np.array_equal(got, want)
     assert got.shape == (n_epochs, 4)
+
+
+def _exchange_worker(rank, world, port, q):
+    from sharding import OccupancyExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    epochs, n_bands = 5, 4
+    ex = OccupancyExchange(epochs, n_bands, "cpu")
+    out = []
+    for i in range(5):  # more steps than slots: every slot is reused
+        blk = ex.local(i)
+        blk.copy_(torch.full((epochs, n_bands), 10 * i + rank, dtype=torch.uint8))
+        out.append(ex.exchange(i).clone())
+    ex.finish()
+    if rank == 1:
+        q.put([o.numpy() for o in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_two_ranks():
+    """sharding.OccupancyExchange (what bench.py runs between launches at N > 1): slot reuse and
+    rank order of the gathered vector."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i, g in enumerate(got):
+        assert g.shape == (10, 4)
+        assert (g[:5] == 10 * i).all() and (g[5:] == 10 * i + 1).all()
+
+
+def test_exchange_without_group_is_a_copy():
+    from sharding import OccupancyExchange
+    ex = OccupancyExchange(3, 2, "cpu")
+    ex.local(0).fill_(7)
+    assert (ex.exchange(0) == 7).all() and ex.gathered(0).shape == (3, 2)
