@@ -693,6 +693,10 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     if (s == 123.456f && p.features != nullptr) p.features[0] = s;  // keeps the accumulation live
     return;
   }
+  // latency-bound stretch with nothing of this wave's in flight behind it, and the workgroup's other
+  // waves waiting at its barriers: outrank the butterflies (+0.6 % at N = 4096, +1.3 % at 2048; the
+  // barrier-free sizes lose 0.5 % with it)
+  if constexpr ((C::OPT & kPrioValu) != 0 && G::XWAVE) __builtin_amdgcn_s_setprio(3);
   const int tid = c.wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int t = tid % T, grp = tid / T;
   const long long epoch = epoch_base + grp;
@@ -836,6 +840,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   // exchange 1 (frame_compute), which is after every wave has passed this point: no barrier here.
   if constexpr (G::XWAVE && C::NBUF == 2) __syncthreads();
   if constexpr (!G::XWAVE) wave_sync();
+  if constexpr ((C::OPT & kPrioValu) != 0 && G::XWAVE) __builtin_amdgcn_s_setprio(0);
 }
 
 // Buffer resource over the IQ window of epoch group `eg` (GROUPS consecutive epochs): anything
