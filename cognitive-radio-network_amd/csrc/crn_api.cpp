@@ -31,6 +31,7 @@ struct crn_handle {
   crn_cfg cfg;
   int variant = 0;
   int groups_per_wg = 0;        // 0 = automatic
+  int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
   // one device slab holding every table
   void *d_tables = nullptr;
@@ -142,13 +143,40 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   if (bins.empty()) bins.push_back(0);
 
   // packed band table for the kernel's LDS copy (layout: crn_kernels.h)
-  std::vector<int> band_tab(512, 0);
+  std::vector<int> band_tab(crn::kBandTabWords, 0);
   for (size_t i = 0; i < seg_begin.size(); i++) band_tab[i] = seg_begin[i];
   for (size_t i = 0; i < seg_lo.size(); i++) {
     band_tab[96 + i] = seg_lo[i];
     band_tab[256 + i] = seg_hi[i];
   }
   std::memcpy(&band_tab[416], cfg->thresh, sizeof(float) * CRN_MAX_BANDS);
+  // Row entries for the register-resident band sums (epoch_close): every thread's accumulators sit
+  // at bins base + 256 d, so a segment is cut at the 256-bin rows and each piece becomes
+  // (row d, band, [lo, hi) inside the row), grouped by row, band-table order kept inside a row.
+  // Only small plans qualify (<= 16 bands, <= 32 / R3 pieces per row); the others keep the LDS walk.
+  h->n_row_entries = 0;
+  {
+    struct Piece { int d, band, lo, hi; };
+    std::vector<Piece> pieces;
+    for (int b = 0; b < cfg->n_bands; b++)
+      for (int sg = seg_begin[b]; sg < seg_begin[b + 1]; sg++)
+        for (int d = seg_lo[sg] >> 8; seg_lo[sg] < seg_hi[sg] && d <= (seg_hi[sg] - 1) >> 8; d++) {
+          const int lo = std::max(seg_lo[sg], 256 * d) - 256 * d, hi = std::min(seg_hi[sg], 256 * (d + 1)) - 256 * d;
+          pieces.push_back({d, b, lo, hi});
+        }
+    // fixed layout, no walk: row d owns words [512 + d * cap, 512 + (d + 1) * cap), cap = 32 / R3;
+    // an unused slot is 0 (span 0)
+    const int cap = crn::kRowEntryWords / R3;
+    bool fits = cfg->n_bands <= 16 && !pieces.empty();
+    std::vector<int> used(16, 0);
+    for (const Piece &pc : pieces)
+      if (++used[pc.d] > cap) fits = false;
+    if (fits) {
+      std::fill(used.begin(), used.end(), 0);
+      for (const Piece &pc : pieces) band_tab[512 + pc.d * cap + used[pc.d]++] = (pc.band << 18) | (pc.lo << 9) | pc.hi;
+      h->n_row_entries = (int)pieces.size();
+    }
+  }
 
   struct Piece { const void *src; size_t bytes; size_t off; };
   std::vector<Piece> pieces = {
@@ -309,8 +337,9 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.decide = c.decide;
   p.ref_band = c.ref_band;
   p.row_mask = h->row_mask;
+  p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;
-  p.ann_out = c.decide == CRN_DECIDE_ANN ? d_out->ann_out : nullptr;
+  p.ann_out = (c.decide == CRN_DECIDE_ANN || h->variant == 17) ? d_out->ann_out : nullptr;  // 17: trace stamps
   p.decision = d_out->decision;
   p.occupancy = d_out->occupancy;
   p.spectrum = d_out->spectrum;

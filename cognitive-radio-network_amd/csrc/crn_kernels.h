@@ -7,6 +7,9 @@
 
 namespace crn {
 
+constexpr int kBandTabWords = 544;   // SenseParams::band_tab, copied to LDS by every workgroup
+constexpr int kRowEntryWords = 32;   // row-entry slots of the register-resident band sums: 32 / R3 per row
+
 enum { CRN_DECIDE_ANN_K = 0, CRN_DECIDE_THRESHOLD_K = 1, CRN_DECIDE_NONE_K = 2 };  // == crn_decide
 
 struct SenseParams {
@@ -23,8 +26,10 @@ struct SenseParams {
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}
   const float *window;     // [N] or null
-  const int *band_tab;        // [512] packed copy of the four tables below, staged into LDS by every workgroup:
-                              //   [0,96) band_seg_begin, [96,256) seg_lo, [256,416) seg_hi, [416,496) thresh (float bits)
+  const int *band_tab;        // [kBandTabWords] packed copy of the tables below, staged into LDS by every workgroup:
+                              //   [0,96) band_seg_begin, [96,256) seg_lo, [256,416) seg_hi, [416,496) thresh (float bits),
+                              //   [512,544) row entries band<<18 | lo<<9 | hi, 32 / R3 slots per 256-bin row, 0 = unused
+                              //   (only when n_row_entries > 0)
   const int *band_seg_begin;  // [n_bands + 1] into seg_lo/seg_hi (segments grouped by band)
   const int *seg_lo;
   const int *seg_hi;
@@ -35,6 +40,7 @@ struct SenseParams {
   int n_bands;
   int decide;
   int ref_band;
+  int n_row_entries;       // > 0: band sums from registers (epoch_close); entries in band_tab
   unsigned row_mask;       // N = 4096: bit d set when some band touches bins [256 d, 256 d + 256)
   // outputs (device, nullable)
   float *features;

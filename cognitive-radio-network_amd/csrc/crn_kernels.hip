@@ -18,6 +18,7 @@
 //   |X|^2 (or |X|) is accumulated per bin in 16 registers per thread over the K frames; the band
 //   reduction, the net and the cascade run once per epoch from LDS.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "crn_kernels.h"
@@ -311,6 +312,8 @@ enum : int {
   kMulti = 512,  // a workgroup streams through several consecutive epoch groups
   kPrioValu = 1024, // s_setprio 1 through the butterflies of passes 1 and 2 (where the prefetch loads issue)
   kNoClose = 2048,  // measurement ablation: the epoch close only folds and resets the accumulators
+  kRegBands = 8192, // epoch close forms the band sums from registers (plans with n_row_entries > 0, no spectrum)
+  kTrace = 4096,    // measurement aid: s_memtime at epoch-close entry / exit into the ann_out buffer
 
 };
 
@@ -642,6 +645,10 @@ CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]
 // Epoch close (reference .cpp:157-261 + the reset at :287-288): K-frame averages -> LDS in natural
 // bin order -> band sums -> features -> decision.  Resets the accumulators for the next epoch.
 // ---------------------------------------------------------------------------------------------
+// LDS behind the exchange buffers and the tw2 table, used by the epoch close: the band table copy,
+// then [8 teams][16] per-team band partials and [8 groups][16] features of the register path.
+constexpr int kCloseLdsBytes = kBandTabWords * 4 + 2 * 8 * 16 * 4;
+
 // LDS address-space views for the epoch close (see epoch_close): ds_* instructions, lgkmcnt only.
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
@@ -669,6 +676,78 @@ CRN_DEV float team_sum(float v, int tid) {
   const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   if constexpr (TEAM == 64) return (r0 + r1) + (r2 + r3);
   else return (tid & 32) ? r2 + r3 : r0 + r1;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int I, int N, class F>
+CRN_DEV void static_for_(F &f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+CRN_DEV void static_for(F &&f) {
+  static_for_<0, N>(f);
+}
+
+// W consecutive table words through the scalar cache into SGPRs (the epoch close must not touch
+// vmcnt, and an LDS read queues behind the other waves' exchange traffic): issue with s_load_row,
+// then s_wait_row before the first use.
+template <int W> struct SWords;
+template <> struct SWords<2> { typedef int T __attribute__((ext_vector_type(2))); };
+template <> struct SWords<4> { typedef int T __attribute__((ext_vector_type(4))); };
+template <> struct SWords<8> { typedef int T __attribute__((ext_vector_type(8))); };
+template <> struct SWords<16> { typedef int T __attribute__((ext_vector_type(16))); };
+template <int W, int BYTE_OFF>
+CRN_DEV typename SWords<W>::T s_load_row(const int *base) {
+  typename SWords<W>::T r;
+  if constexpr (W == 2) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r) : "s"(base), "n"(BYTE_OFF));
+  if constexpr (W == 4) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(base), "n"(BYTE_OFF));
+  if constexpr (W == 8) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(base), "n"(BYTE_OFF));
+  if constexpr (W == 16) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(base), "n"(BYTE_OFF));
+  return r;
+}
+template <class V>
+CRN_DEV void s_wait_row(V &r) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+}
+
+// The reference's 4-5-3 sigmoid network and cascade (CE_Predictive_Node.cpp:200-261) on one lane.
+CRN_DEV void ann_decide(const SenseParams &p, long long epoch, float nf, float ch1, float ch2, float ch3) {
+  // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
+  const double f1 = (double)nf, f2 = (double)ch1, f3 = (double)ch2, f4 = (double)ch3;
+  double hid[6];
+#pragma unroll
+  for (int j = 1; j <= 5; j++) {  // .cpp:214-220
+    double s = p.ann_w_ih[0 * 6 + j];
+    s += f1 * p.ann_w_ih[1 * 6 + j];
+    s += f2 * p.ann_w_ih[2 * 6 + j];
+    s += f3 * p.ann_w_ih[3 * 6 + j];
+    s += f4 * p.ann_w_ih[4 * 6 + j];
+    hid[j] = 1.0 / (1.0 + exp(-s));
+  }
+  double o[4];
+#pragma unroll
+  for (int k = 1; k <= 3; k++) {  // .cpp:229-235
+    double s = p.ann_w_ho[0 * 4 + k];
+#pragma unroll
+    for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
+    o[k] = 1.0 / (1.0 + exp(-s));
+  }
+  // .cpp:245-261 cascade
+  int d = 0;
+  if (o[1] >= p.ann_threshold) d = 1;
+  else if (o[2] >= p.ann_threshold) d = 2;
+  else if (o[3] >= p.ann_threshold) d = 3;
+  if (p.ann_out != nullptr) {
+    p.ann_out[epoch * 3 + 0] = o[1];
+    p.ann_out[epoch * 3 + 1] = o[2];
+    p.ann_out[epoch * 3 + 2] = o[3];
+  }
+  if (p.decision != nullptr) p.decision[epoch] = d;
+  if (p.occupancy != nullptr)
+    for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
 }
 
 template <class C>
@@ -702,6 +781,17 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   const long long epoch = epoch_base + grp;
   const bool active = epoch < p.n_epochs;
   const int a = t / R3, m_lo = t % R3;
+  [[maybe_unused]] unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
+  if constexpr ((C::OPT & kTrace) != 0) {
+    // [epoch][3] uint64: entry of the group's first wave; its later stamps as four 16-bit deltas
+    // (band sums done, barrier passed, features ready, exit); entry of the group's last wave
+    unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
+    tr0 = __builtin_amdgcn_s_memtime();
+    if (active && tr != nullptr) {
+      if (t == 0) tr[epoch * 3 + 0] = tr0;
+      if (t == T - 1) tr[epoch * 3 + 2] = tr0;
+    }
+  }
   // Energy mode: the division by K is applied to the band sums (and to the per-bin values only
   // when a spectrum is requested) — sixteen IEEE divides per thread per epoch were half a frame's
   // worth of VALU work.  Sum-then-divide differs from the reference order (divide-then-sum) by
@@ -714,132 +804,204 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   const lds_i32 *tab = reinterpret_cast<const lds_i32 *>(tab_off);
   const lds_f32 *thr = reinterpret_cast<const lds_f32 *>(tab_off + 416 * 4);
   lds_f32 *spec = reinterpret_cast<lds_f32 *>(gb_off);    // N + N/16 floats
-  lds_f32 *feat = spec + spec_phys(N);                    // CRN_MAX_BANDS floats
-  if constexpr (G::XWAVE) __syncthreads();
-  else wave_sync();
+  lds_f32 *featl = spec + spec_phys(N);                   // CRN_MAX_BANDS floats (LDS path)
+  constexpr int TEAM = G::TEAM;
+  constexpr int TPG = T / TEAM;  // teams (waves) per group
+  const int lane = t % TEAM;
+  lds_f32 *part = reinterpret_cast<lds_f32 *>(tab_off + kBandTabWords * 4);  // [256 / TEAM][16]
+  [[maybe_unused]] const lds_f32 *feat = nullptr;
+  // Two forms of the close, chosen per launch (one kernel holding both spilled in the frame loop):
+  if constexpr ((C::OPT & kRegBands) != 0) {
+    // Band sums straight from the accumulator registers: no LDS image of the spectrum, no barrier
+    // before it (nothing aliases the exchange buffers) and none after the decision.  Thread bins are
+    // base_j + 256 d; the host cut the band plan at the 256-bin rows (crn_api.cpp), so each entry is
+    // (row d, band, [lo, hi) in the row): masked add over j, DPP team sum, lane `band` keeps it.
+    // LDS round trips are what this block avoids (an LDS read here queues behind the exchange
+    // traffic of the CU's other waves: measured ~500 ticks each): the entries come through the
+    // scalar cache, the features stay in lanes, the thresholds are fetched first and used last.
+    constexpr int CAP = kRowEntryWords / R3;  // entry slots per row
+    constexpr auto row_live = [](int d) {
+      return !((C::OPT & kRows) != 0 && R3 == 16 && !MAG) || ((kRefPlanRows >> d) & 1) != 0;
+    };
+    float thr_lane = 0.f;
+    if constexpr (TPG == 1) thr_lane = thr[lane & 15];  // fetched first, used last
+    // one row's entries at a time, the next row's load in flight meanwhile: holding all of them
+    // costs SGPRs the frame loop needs (the spill lanes' VGPR pushed a loop address to scratch)
+    constexpr auto next_live = [](int d) {
+      for (int x = d + 1; x < R3; x++)
+        if (!((C::OPT & kRows) != 0 && R3 == 16 && !MAG) || ((kRefPlanRows >> x) & 1) != 0) return x;
+      return (int)R3;
+    };
+    constexpr int kFirst = next_live(-1);
+    float fsum = 0.f;
+    typename SWords<CAP>::T ent_next = s_load_row<CAP, (512 + kFirst * CAP) * 4>(p.band_tab);
+    static_for<R3>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      if constexpr (row_live(d)) {
+        typename SWords<CAP>::T ent = ent_next;
+        s_wait_row(ent);
+        constexpr int dn = next_live(d);
+        if constexpr (dn < R3) ent_next = s_load_row<CAP, (512 + dn * CAP) * 4>(p.band_tab);
 #pragma unroll
-  for (int j = 0; j < J; j++)
+        for (int e = 0; e < CAP; e++) {
+          const int w = ent[e];
+          if (w != 0) {  // uniform; 0 = unused slot
+            const int band = w >> 18, lo = (w >> 9) & 511, span = (w & 511) - lo;
+            float v = 0.f;
 #pragma unroll
-    for (int d = 0; d < R3; d++) {
-      // the row-pruned kernel never accumulates (or reads back) the other rows
-      if constexpr ((C::OPT & kRows) != 0 && R3 == 16 && !MAG) {
-        if (!((kRefPlanRows >> d) & 1)) continue;
-      }
-      const int k = a + 16 * (m_lo * J + j) + 256 * d;
-      spec[spec_phys(k)] = acc[j * R3 + d];
-    }
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;  // .cpp:287
-  if constexpr (G::XWAVE) __syncthreads();
-  else wave_sync();
-
-  if (p.spectrum != nullptr && active) {
-    float *dst = p.spectrum + epoch * N;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float x = spec[spec_phys(t + T * r)];
-      dst[t + T * r] = MAG ? x : __fdiv_rn(x, Kf);
-    }
-  }
-
-  // band sums (reference .cpp:173-191), one team of lanes per band.  This stretch is pure latency
-  // (the wave has no loads in flight beyond its prefetched frame), so: table walk from LDS, four
-  // independent bin reads per trip, DPP/readlane reduction instead of ds_bpermute shuffles.
-  {
-    constexpr int TEAM = G::TEAM;
-    constexpr int TEAMS = T / TEAM;
-    const int team = t / TEAM, lane = t % TEAM;
-    for (int b = team; b < p.n_bands; b += TEAMS) {
-      float s = 0.f;
-      const int s0 = tab[b], s1 = tab[b + 1];
-      for (int sg = s0; sg < s1; sg++) {
-        const int lo = tab[96 + sg], hi = tab[256 + sg];
-        for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int k = k0 + i * TEAM;
-            const float x = spec[spec_phys(k < hi ? k : lo)];
-            v[i] = k < hi ? x : 0.f;
+            for (int j = 0; j < J; j++) {
+              const int base = a + 16 * (m_lo * J + j);
+              v += (unsigned)(base - lo) < (unsigned)span ? acc[j * R3 + d] : 0.f;
+            }
+            v = team_sum<TEAM>(v, tid);
+            fsum += lane == band ? v : 0.f;
           }
-          s += (v[0] + v[1]) + (v[2] + v[3]);
         }
       }
-      s = team_sum<TEAM>(s, tid);
-      if (lane == 0) feat[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
+    });
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;  // .cpp:287
+    if constexpr ((C::OPT & kTrace) != 0) tr1 = __builtin_amdgcn_s_memtime();
+    if constexpr (TPG > 1) {
+      if (lane < 16) part[(tid / TEAM) * 16 + lane] = fsum;
+      __syncthreads();
+      if constexpr ((C::OPT & kTrace) != 0) tr2 = __builtin_amdgcn_s_memtime();
+      if (t < TEAM && lane < 16) {
+        thr_lane = thr[lane];  // same LDS round trip as the partials
+        fsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < TPG; w++) fsum += part[(grp * TPG + w) * 16 + lane];
+      }
     }
-  }
-  if constexpr (G::XWAVE) __syncthreads();
-  else wave_sync();
+    if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
+    // the first team of the group stores and decides; lane b holds band b (n_bands <= 16)
+    if (t < TEAM) {
+      const float f = MAG ? fsum * fsum : __fdiv_rn(fsum, Kf);  // .cpp:194-197
+      const int half = TEAM == 32 ? (tid & 32) : 0;             // two groups share a wave at T = 32
+      auto from_lane = [&](int b) {
+        const float lo_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), b));
+        if constexpr (TEAM == 32) {
+          const float hi_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 32 + b));
+          return half ? hi_half : lo_half;
+        }
+        return lo_half;
+      };
+      const bool in = lane < p.n_bands;
+      if (p.decide == CRN_DECIDE_ANN_K) {
+        const float nf = from_lane(0), ch1 = from_lane(1), ch2 = from_lane(2), ch3 = from_lane(3);
+        if (active && t == 0) ann_decide(p, epoch, nf, ch1, ch2, ch3);
+      } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
+        const float ref = p.ref_band >= 0 ? from_lane(p.ref_band) : 1.0f;
+        const bool occ = active && in && f > thr_lane * ref;
+        if (active && in && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + lane] = (uint8_t)occ;
+        unsigned long long m = __ballot(occ);
+        if constexpr (TEAM == 32) m = (m >> half) & 0xffffffffull;
+        if (active && t == 0 && p.decision != nullptr) p.decision[epoch] = __popcll(m);
+      } else if (active) {
+        if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
+        if (in && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + lane] = 0;
+      }
+      if (active && in && p.features != nullptr) p.features[epoch * p.n_bands + lane] = f;
+    }
+  } else {
+    if constexpr (G::XWAVE) __syncthreads();
+    else wave_sync();
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+      for (int d = 0; d < R3; d++) {
+        // the row-pruned kernel never accumulates (or reads back) the other rows
+        if constexpr ((C::OPT & kRows) != 0 && R3 == 16 && !MAG) {
+          if (!((kRefPlanRows >> d) & 1)) continue;
+        }
+        const int k = a + 16 * (m_lo * J + j) + 256 * d;
+        spec[spec_phys(k)] = acc[j * R3 + d];
+      }
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;  // .cpp:287
+    if constexpr (G::XWAVE) __syncthreads();
+    else wave_sync();
 
-  if (active) {
-    if (p.features != nullptr)
-      for (int b = t; b < p.n_bands; b += T) p.features[epoch * p.n_bands + b] = feat[b];
+    if (p.spectrum != nullptr && active) {
+      float *dst = p.spectrum + epoch * N;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float x = spec[spec_phys(t + T * r)];
+        dst[t + T * r] = MAG ? x : __fdiv_rn(x, Kf);
+      }
+    }
 
-    if (p.decide == CRN_DECIDE_ANN_K) {
-      if (t == 0) {
-        // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
-        const double f1 = (double)feat[0], f2 = (double)feat[1], f3 = (double)feat[2], f4 = (double)feat[3];
-        double hid[6];
+    // band sums (reference .cpp:173-191), one team of lanes per band.  This stretch is pure latency
+    // (the wave has no loads in flight beyond its prefetched frame), so: table walk from LDS, four
+    // independent bin reads per trip, DPP/readlane reduction instead of ds_bpermute shuffles.
+    {
+      const int team = t / TEAM;
+      for (int b = team; b < p.n_bands; b += TPG) {
+        float s = 0.f;
+        const int s0 = tab[b], s1 = tab[b + 1];
+        for (int sg = s0; sg < s1; sg++) {
+          const int lo = tab[96 + sg], hi = tab[256 + sg];
+          for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
+            float v[4];
 #pragma unroll
-        for (int j = 1; j <= 5; j++) {  // .cpp:214-220
-          double s = p.ann_w_ih[0 * 6 + j];
-          s += f1 * p.ann_w_ih[1 * 6 + j];
-          s += f2 * p.ann_w_ih[2 * 6 + j];
-          s += f3 * p.ann_w_ih[3 * 6 + j];
-          s += f4 * p.ann_w_ih[4 * 6 + j];
-          hid[j] = 1.0 / (1.0 + exp(-s));
+            for (int i = 0; i < 4; i++) {
+              const int k = k0 + i * TEAM;
+              const float x = spec[spec_phys(k < hi ? k : lo)];
+              v[i] = k < hi ? x : 0.f;
+            }
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+          }
         }
-        double o[4];
-#pragma unroll
-        for (int k = 1; k <= 3; k++) {  // .cpp:229-235
-          double s = p.ann_w_ho[0 * 4 + k];
-#pragma unroll
-          for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
-          o[k] = 1.0 / (1.0 + exp(-s));
+        s = team_sum<TEAM>(s, tid);
+        if (lane == 0) featl[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
+      }
+    }
+    if constexpr (G::XWAVE) __syncthreads();
+    else wave_sync();
+
+    feat = featl;
+
+    // LDS path: the first team of the group stores and decides.
+    if (active && t < TEAM) {
+      if (p.features != nullptr)
+        for (int b = t; b < p.n_bands; b += TEAM) p.features[epoch * p.n_bands + b] = feat[b];
+
+      if (p.decide == CRN_DECIDE_ANN_K) {
+        if (t == 0) ann_decide(p, epoch, feat[0], feat[1], feat[2], feat[3]);
+      } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
+        // lane i takes bands i, i + TEAM, ...; the count of occupied bands is a ballot, not a serial walk
+        {
+          const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
+          int cnt = 0;
+          for (int b0 = 0; b0 < p.n_bands; b0 += TEAM) {
+            const int b = b0 + t;
+            const bool in = b < p.n_bands;
+            const bool occ = in && feat[in ? b : 0] > thr[in ? b : 0] * ref;
+            if (in && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + b] = (uint8_t)occ;
+            unsigned long long m = __ballot(occ);
+            if constexpr (TEAM == 32) m = (m >> (tid & 32)) & 0xffffffffull;
+            cnt += __popcll(m);
+          }
+          if (t == 0 && p.decision != nullptr) p.decision[epoch] = cnt;
         }
-        // .cpp:245-261 cascade
-        int d = 0;
-        if (o[1] >= p.ann_threshold) d = 1;
-        else if (o[2] >= p.ann_threshold) d = 2;
-        else if (o[3] >= p.ann_threshold) d = 3;
-        if (p.ann_out != nullptr) {
-          p.ann_out[epoch * 3 + 0] = o[1];
-          p.ann_out[epoch * 3 + 1] = o[2];
-          p.ann_out[epoch * 3 + 2] = o[3];
-        }
-        if (p.decision != nullptr) p.decision[epoch] = d;
+      } else {
+        if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
         if (p.occupancy != nullptr)
-          for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
+          for (int b = t; b < p.n_bands; b += TEAM) p.occupancy[epoch * p.n_bands + b] = 0;
       }
-    } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
-      // the first team of the group decides: lane i takes bands i, i + TEAM, ...; the count of
-      // occupied bands is a ballot, not a serial walk
-      constexpr int TEAM = G::TEAM;
-      if (t < TEAM) {
-        const float ref = p.ref_band >= 0 ? feat[p.ref_band] : 1.0f;
-        int cnt = 0;
-        for (int b0 = 0; b0 < p.n_bands; b0 += TEAM) {
-          const int b = b0 + t;
-          const bool in = b < p.n_bands;
-          const bool occ = in && feat[in ? b : 0] > thr[in ? b : 0] * ref;
-          if (in && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + b] = (uint8_t)occ;
-          unsigned long long m = __ballot(occ);
-          if constexpr (TEAM == 32) m = (m >> (tid & 32)) & 0xffffffffull;
-          cnt += __popcll(m);
-        }
-        if (t == 0 && p.decision != nullptr) p.decision[epoch] = cnt;
-      }
-    } else {
-      if (t == 0 && p.decision != nullptr) p.decision[epoch] = 0;
-      if (p.occupancy != nullptr)
-        for (int b = t; b < p.n_bands; b += T) p.occupancy[epoch * p.n_bands + b] = 0;
     }
   }
   // With one exchange buffer the next epoch's first frame syncs the workgroup before it writes
   // exchange 1 (frame_compute), which is after every wave has passed this point: no barrier here.
   if constexpr (G::XWAVE && C::NBUF == 2) __syncthreads();
   if constexpr (!G::XWAVE) wave_sync();
+  if constexpr ((C::OPT & kTrace) != 0) {
+    unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
+    const unsigned long long tr4 = __builtin_amdgcn_s_memtime();
+    auto d16 = [&](unsigned long long x) { return (x - tr0) > 0xFFFFull ? 0xFFFFull : (x - tr0); };
+    if (active && tr != nullptr && t == 0)
+      tr[epoch * 3 + 1] = d16(tr1) | (d16(tr2) << 16) | (d16(tr3) << 32) | (d16(tr4) << 48);
+  }
   if constexpr ((C::OPT & kPrioValu) != 0 && G::XWAVE) __builtin_amdgcn_s_setprio(0);
 }
 
@@ -896,6 +1058,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
     tab[tid] = p.band_tab[tid];
     tab[tid + 256] = p.band_tab[tid + 256];
+    if (tid < kBandTabWords - 512) tab[tid + 512] = p.band_tab[tid + 512];  // row entries
   }
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
@@ -1067,7 +1230,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
                      !(C::WIN && p.frame_stride * 2 == G::N);
   const int epw = multi ? p.groups_per_wg : 1;
   const unsigned grid = (unsigned)((n_groups + epw - 1) / epw);
-  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + 512 * sizeof(int);
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
   if (lds > 48 * 1024) {
@@ -1079,17 +1242,33 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// The register form of the epoch close applies to band plans the host could cut into row entries
+// (crn_api.cpp) when no per-bin spectrum is stored.
+static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
+
 // Default configuration of every size: all mode / window / short-frame combinations.
 template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
+  // small band plan, no spectrum: band sums from registers.  Not at N = 512: 16 entry slots x 8 bins
+  // per thread and row unroll into a close that pushes frame-loop values to scratch (-3 %).
+  const bool regb = reg_bands(p);
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
+#define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
   if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
-  if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
   if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
+  if constexpr (R3 >= 4) {
+    if (regb) {
+      if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
+      if (full) CRN_GO_R(false, false, true);
+      CRN_GO_R(false, false, false);
+    }
+  }
+  if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
   if (full) CRN_GO(false, false, true);
   CRN_GO(false, false, false);
 #undef CRN_GO
+#undef CRN_GO_R
 }
 
 // A/B variants: compiled for the headline shape only (N = 4096, energy mode, no window, L = N).
@@ -1118,6 +1297,7 @@ static constexpr VariantDesc kVariants[] = {
     /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: butterflies only (no reload, no LDS exchange)
     /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only, 3 workgroups/CU
     /* 16 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: the default with the epoch close reduced to an accumulator reset
+    /* 17 */ {1, 1, 1, 1, 4, 0, 1},  // measurement aid: the default + s_memtime stamps of the epoch close in ann_out
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -1139,14 +1319,17 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
-      case 2: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
+      case 2:
+        if (reg_bands(p))
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
       case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, kPair>(p, mag, win, stream);
       case 7:
-        if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kMulti>(p, mag, win, stream);
+        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kMulti>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
       case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, kPair>(p, mag, win, stream);
@@ -1155,12 +1338,15 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
       case 13:
         // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
-        if (p.spectrum == nullptr && (p.row_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti>(p, mag, win, stream);
+        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
+        if (reg_bands(p))
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
-      case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kNoClose>(p, mag, win, stream);
+      case 17: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kTrace>(p, mag, win, stream);
+      case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
     }
   }
   return hipErrorInvalidValue;
@@ -1201,7 +1387,7 @@ void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int 
   *threads = 256;
   *epochs_per_block = groups;
   (void)tl;
-  *lds_bytes = (groups * nbuf * 16 * (t + r3) + 16 * r3) * 8 + 2048;
+  *lds_bytes = (groups * nbuf * 16 * (t + r3) + 16 * r3) * 8 + kCloseLdsBytes;
 }
 
 // ---------------------------------------------------------------------------------------------

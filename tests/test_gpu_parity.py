@@ -182,8 +182,8 @@ def test_kernel_variants_agree(built):
     n_epochs = 9
     iq, _ = signals.make_epochs(cfg, n_epochs, seed=77)
     base = None
-    for v in range(0, 17):
-        if v in (11, 12, 14, 15, 16):
+    for v in range(0, 18):
+        if v in (11, 12, 14, 15, 16, 17):
             continue  # measurement ablations: not a sensing result
         s = cs.Sensor(cfg)
         s.set_variant(v)
@@ -469,7 +469,9 @@ def test_row_pruned_fast_path_matches_oracle(built):
     for got in (fast, full):
         assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
         assert np.array_equal(got["occupancy"], want["occupancy"])
-    assert np.array_equal(fast["features"], full["features"])  # same arithmetic for the bins that count
+    # same bins, same per-bin arithmetic; the band sums are formed from registers (fast) or from the LDS
+    # image (full), i.e. in a different order
+    assert np.allclose(fast["features"], full["features"], rtol=2e-6, atol=0)
     # a band in row 12 (bins 3072..3327) is outside the reference plan's rows
     other = cs.cfg_energy_scaled(4096, 4.0)
     other.segs[3].lo, other.segs[3].hi = 3100, 3300
