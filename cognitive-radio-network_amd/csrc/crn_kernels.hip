@@ -770,6 +770,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       acc[i] = 0.f;
     }
     if (s == 123.456f && p.features != nullptr) p.features[0] = s;  // keeps the accumulation live
+    if constexpr ((C::OPT & kTrace) != 0 && G::XWAVE) __syncthreads();  // variant 18: what one barrier per epoch costs
     return;
   }
   // latency-bound stretch with nothing of this wave's in flight behind it, and the workgroup's other
@@ -1298,6 +1299,7 @@ static constexpr VariantDesc kVariants[] = {
     /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only, 3 workgroups/CU
     /* 16 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: the default with the epoch close reduced to an accumulator reset
     /* 17 */ {1, 1, 1, 1, 4, 0, 1},  // measurement aid: the default + s_memtime stamps of the epoch close in ann_out
+    /* 18 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: 16 plus one workgroup barrier per epoch
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -1346,6 +1348,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
       case 17: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kTrace>(p, mag, win, stream);
+      case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
     }
   }

@@ -30,6 +30,7 @@ res = {}
 cases = [("all outputs", 0, full), ("occupancy only", 0, only_occ), ("no outputs", 0, none)]
 if fft == 4096:
     cases.append(("no close (v16)", 16, full))
+    cases.append(("v16 + barrier", 18, full))
 for rep in range(3):
     for name, var, outs in cases:
         s.set_variant(var)
