@@ -1,0 +1,75 @@
+"""cfg3 at full size (BASELINE.json configs[3]): >= 1e6 reference-mode decision epochs
+(N = 512, |X| mean over 10 frames, square of sum, fused 4-5-3 ANN in fp64, cascade) on the GPU, every
+one of them compared with the CPU restatement run on the same bytes: decisions and occupancy bit-exact
+outside the near-threshold margin band, the in-band count reported.  Runs in chunks so that the host
+never holds more than ~5 GiB; the oracle uses all host cores."""
+import os
+
+import numpy as np
+import pytest
+
+import crnsense as cs
+import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+
+TOTAL_EPOCHS = 1_048_576
+CHUNK = 131_072
+MARGIN = 1e-3          # |O[k] - 0.8| below this = near-threshold (CE_Predictive_Node.cpp:246-256 compare)
+
+
+def test_cfg3_million_epochs_decisions_bit_exact(built):
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = cs.cfg_reference()
+    spe = cs.samples_per_epoch(cfg)
+    sensor = cs.Sensor(cfg)
+    iq = torch.zeros(CHUNK * spe * 2, dtype=torch.float32, device=dev)
+    truth = torch.zeros(CHUNK, dtype=torch.int32, device=dev)
+    feats = torch.zeros(CHUNK, 4, dtype=torch.float32, device=dev)
+    ann = torch.zeros(CHUNK, 3, dtype=torch.float64, device=dev)
+    dec = torch.zeros(CHUNK, dtype=torch.int32, device=dev)
+    occ = torch.zeros(CHUNK, 4, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
+            "occupancy": occ.data_ptr(), "spectrum": 0}
+    cores = os.cpu_count() or 1
+    n_total = n_near = n_mismatch_outside = n_mismatch_inside = n_driven_mismatch = 0
+    max_ann_err = 0.0
+    max_feat_rel = 0.0
+    hist = np.zeros(4, np.int64)
+    for c in range(TOTAL_EPOCHS // CHUNK):
+        sensor.synth_fill_device(iq.data_ptr(), CHUNK, spe, seed=0xC0FFEE + 3 + 7919 * c,
+                                 truth_ptr=truth.data_ptr(), stream=stream)
+        sensor.run_device(iq.data_ptr(), CHUNK, cfg.fft_len, outs, stream=stream)
+        torch.cuda.synchronize()
+        host = iq.cpu().numpy()
+        want = orc.run(cfg, host, CHUNK, n_threads=cores)
+        g_dec, g_occ, g_ann, g_feat = dec.cpu().numpy(), occ.cpu().numpy(), ann.cpu().numpy(), feats.cpu().numpy()
+        near = (np.abs(want["ann_out"] - cfg.ann_threshold) < MARGIN).any(axis=1)
+        bad = (g_dec != want["decision"]) | (g_occ != want["occupancy"]).any(axis=1)
+        n_total += CHUNK
+        n_near += int(near.sum())
+        n_mismatch_outside += int((bad & ~near).sum())
+        n_mismatch_inside += int((bad & near).sum())
+        n_driven_mismatch += int((g_dec != truth.cpu().numpy()).sum())
+        max_ann_err = max(max_ann_err, float(np.abs(g_ann - want["ann_out"]).max()))
+        max_feat_rel = max(max_feat_rel, float((np.abs(g_feat - want["features"]) /
+                                                np.maximum(np.abs(want["features"]), 1e-30)).max()))
+        hist += np.bincount(want["decision"], minlength=4)[:4]
+    sensor.close()
+    report = (f"cfg3: {n_total} epochs (N=512, K=10, {n_total * spe} samples) GPU vs CPU restatement on the same bytes\n"
+              f"  decisions by state (none, CH1, CH2, CH3): {hist.tolist()}\n"
+              f"  near-threshold epochs (|O[k]-0.8| < {MARGIN}): {n_near}\n"
+              f"  decision/occupancy mismatches outside the margin band: {n_mismatch_outside}\n"
+              f"  decision/occupancy mismatches inside the margin band: {n_mismatch_inside}\n"
+              f"  epochs whose decision differs from the driven occupancy pattern: {n_driven_mismatch}\n"
+              f"  max |ann_out - oracle| = {max_ann_err:.3e}; max feature rel. error = {max_feat_rel:.3e}\n")
+    print(report)
+    out_dir = os.environ.get("CRN_EVIDENCE_DIR")
+    if out_dir and os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "cfg3_decisions.txt"), "w").write(report)
+    assert n_total >= 1_000_000
+    assert n_mismatch_outside == 0
+    assert max_feat_rel < 1e-5 and max_ann_err < 1e-6
+    assert hist.min() > 0, "every state must occur"

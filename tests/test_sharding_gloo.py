@@ -27,15 +27,24 @@ def test_shard_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, n_epochs, q):
+def _make_cfg(kind):
+    if kind == "scan64":  # cfg4's shard unit: Welch PSD, 64 channels per stream
+        cfg = cs.cfg_welch(1024, 4, 64)
+        for b in range(64):
+            cfg.thresh[b] = 1e-2
+        return cfg
+    return cs.cfg_energy_scaled(1024, 4.0)
+
+
+def _worker(rank, world, port, n_epochs, q, kind="energy"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    cfg = _make_cfg(kind)
     iq, _ = signals.make_epochs(cfg, n_epochs, seed=31337)          # same on every rank
     lo, hi = shard(n_epochs, rank, world)
     spe = cs.samples_per_epoch(cfg)
-    mine = orc.run(cfg, iq[lo * spe * 2:hi * spe * 2], hi - lo)      # this rank's streams only
+    mine = orc.run(cfg, iq[lo * spe * 2:(hi * spe + cs.samples_needed(cfg, 0)) * 2], hi - lo)  # this rank's streams only
     occ_all = gather_occupancy(torch.from_numpy(mine["occupancy"]))
     if rank == 0:
         q.put(occ_all.numpy().copy())
@@ -43,25 +52,27 @@ def _worker(rank, world, port, n_epochs, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process(built):
+@pytest.mark.parametrize("kind,n_bands", [("energy", 4), ("scan64", 64)])
+def test_two_rank_gather_equals_single_process(built, kind, n_bands):
     world, n_epochs = 2, 12
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_epochs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_epochs, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    cfg = _make_cfg(kind)
     iq, picks = signals.make_epochs(cfg, n_epochs, seed=31337)
     want = orc.run(cfg, iq, n_epochs)["occupancy"]
     assert np.array_equal(got, want)
-    assert got.shape == (n_epochs, 4)
+    assert got.shape == (n_epochs, n_bands)
+    assert got.any() and not got.all()
 
 
 def _exchange_worker(rank, world, port, q):

@@ -10,6 +10,9 @@ os.makedirs(DST, exist_ok=True)
 for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("bench_headline.json", f"{tag}_bench_headline.json"),
                  ("bench_cfg1_1024.json", f"{tag}_bench_cfg1_1024pt.json"), ("bench_cfg3_ref512.json", f"{tag}_bench_cfg3_ref512.json"),
                  ("bench_cfg2_welch.json", f"{tag}_bench_cfg2_welch.json"), ("host_rate.txt", f"{tag}_host_buffer_rate.txt"),
+                 ("bench_unpruned.json", f"{tag}_bench_headline_unpruned.json"), ("bench_noclose.json", f"{tag}_bench_ablation_no_epoch_close.json"),
+                 ("bench_e512.json", f"{tag}_bench_energy_512pt.json"), ("bench_e2048.json", f"{tag}_bench_energy_2048pt.json"),
+                 ("membw_policy.txt", f"{tag}_stream_ceiling_policy.txt"), ("cfg3_decisions.txt", f"{tag}_cfg3_decisions_1M_epochs.txt"),
                  ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("smoke.log", f"{tag}_smoke.log")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
@@ -27,18 +30,28 @@ def mean_counter(sub, name):
     return sum(v[-5:]) / len(v[-5:]) if v else None
 
 
-fetch, write = mean_counter("pmc_fetch", "FETCH_SIZE"), mean_counter("pmc_write", "WRITE_SIZE")
-head = json.load(open(os.path.join(SRC, "bench_headline.json")))
-if fetch is not None:
-    E = head["config"]["epochs_per_gpu"]
-    out = {
-        "_how": "rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes "
-                "(--kernel-trace only) over `python3 bench.py --steps 5 --warmup 20 --cpu-epochs 0`; FETCH_SIZE is KiB and on "
-                "gfx950 tallies each 128-B request as 64 B, so x2 (MI355X_MICROARCH.md, HBM section); the x2 was re-calibrated for "
-                "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt)",
-        "energy4096": {"epochs": E, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-                        "hbm_bytes_per_launch": int(fetch * 1024 * 2 + (write or 0) * 1024),
-                        "algorithmic_bytes_per_launch": head["config"]["bytes_per_gpu_per_step"]}}
+HOW = ("rocprofv3 --pmc FETCH_SIZE [GRBM_GUI_ACTIVE] and --pmc WRITE_SIZE [TCC_HIT_sum TCC_MISS_sum] in separate passes "
+       "(--kernel-trace only) over `python3 bench.py --steps 5 --warmup 20 --cpu-epochs 0 <workload flags>`; FETCH_SIZE is KiB and on "
+       "gfx950 tallies each 128-B request as 64 B, so x2 (MI355X_MICROARCH.md, HBM section); the x2 was re-calibrated for "
+       "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt)")
+out = {"_how": HOW}
+# key = bench.py's f"{mode}{N}"; the unpruned 4096-pt kernel is recorded for the record only
+for key, sub, bench in (("energy4096", "", "bench_headline.json"), ("energy1024", "_cfg1", "bench_cfg1_1024.json"),
+                        ("ref512", "_cfg3", "bench_cfg3_ref512.json"), ("welch4096", "_cfg2", "bench_cfg2_welch.json"),
+                        ("energy512", "_e512", "bench_e512.json"), ("energy2048", "_e2048", "bench_e2048.json"),
+                        ("energy4096_unpruned", "_unpruned", "bench_unpruned.json")):
+    fetch, write = mean_counter("pmc_fetch" + sub, "FETCH_SIZE"), mean_counter("pmc_write" + sub, "WRITE_SIZE")
+    bj = os.path.join(SRC, bench)
+    if fetch is None or not os.path.exists(bj):
+        continue
+    try:
+        head = json.load(open(bj))
+    except Exception:
+        continue
+    out[key] = {"epochs": head["config"]["epochs_per_gpu"], "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                "hbm_bytes_per_launch": int(fetch * 1024 * 2 + (write or 0) * 1024),
+                "algorithmic_bytes_per_launch": head["config"]["bytes_per_gpu_per_step"]}
+    print(key, out[key])
+if len(out) > 1:
     json.dump(out, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
-    print(out["energy4096"])
 print(sorted(os.listdir(DST)))
