@@ -23,7 +23,7 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
-    "crn_synth_fill_device", "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy",
     "crn_last_error", "crn_abi_version",
@@ -60,6 +60,16 @@ class EpochResult(C.Structure):
                 ("occupancy", C.c_uint8 * CRN_MAX_BANDS)]
 
 
+PU_UNIFORM, PU_MARKOV_AS_WRITTEN, PU_MARKOV_INTENDED = 0, 1, 2
+SIG_TONES, SIG_CW, SIG_BAND_NOISE = 0, 1, 2
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("noise_power", C.c_float), ("signal_rms", C.c_float),
+                ("tones_per_band", C.c_int32), ("pu_model", C.c_int32), ("signal_kind", C.c_int32),
+                ("n_streams", C.c_int32)]
+
+
 class CrnError(RuntimeError):
     pass
 
@@ -87,6 +97,8 @@ def lib():
                                          C.POINTER(Out)]
         L.crn_synth_fill_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
                                             C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+        L.crn_synth_fill_device_ex.argtypes = [C.c_void_p, C.POINTER(SynthCfg), C.c_void_p, C.c_int64, C.c_int64,
+                                               C.c_void_p, C.c_void_p]
         L.crn_sense_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
@@ -196,6 +208,12 @@ class Sensor:
         check(lib().crn_synth_fill_device(self._h, iq_ptr, n_epochs, spe, seed, noise_power, signal_rms,
                                           tones, C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
               "crn_synth_fill_device")
+
+    def synth_fill_device_ex(self, iq_ptr, n_epochs, spe, sc, truth_ptr=0, stream=0):
+        """sc: SynthCfg (traffic model, signal kind, streams)."""
+        check(lib().crn_synth_fill_device_ex(self._h, C.byref(sc), iq_ptr, n_epochs, spe,
+                                             C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
+              "crn_synth_fill_device_ex")
 
 
 class Ingest:

@@ -412,18 +412,44 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
 int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs, int64_t samples_per_epoch,
                           uint64_t seed, float noise_power, float signal_rms, int32_t tones_per_band,
                           int32_t *d_truth, void *stream) {
-  if (!h || !d_iq) return crn::fail(CRN_ERR_ARG, "null handle / IQ pointer");
+  crn_synth_cfg sc{};
+  sc.seed = seed;
+  sc.noise_power = noise_power;
+  sc.signal_rms = signal_rms;
+  sc.tones_per_band = tones_per_band;
+  sc.pu_model = CRN_PU_UNIFORM;
+  sc.signal_kind = CRN_SIG_TONES;
+  sc.n_streams = 1;
+  return crn_synth_fill_device_ex(h, &sc, d_iq, n_epochs, samples_per_epoch, d_truth, stream);
+}
+
+int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq, int64_t n_epochs,
+                             int64_t samples_per_epoch, int32_t *d_truth, void *stream) {
+  if (!h || !d_iq || !sc) return crn::fail(CRN_ERR_ARG, "null handle / configuration / IQ pointer");
   if (n_epochs < 0 || samples_per_epoch < 1) return crn::fail(CRN_ERR_ARG, "bad sizes");
-  if (tones_per_band < 0 || noise_power < 0.f) return crn::fail(CRN_ERR_ARG, "bad signal parameters");
+  if (sc->tones_per_band < 0 || sc->noise_power < 0.f) return crn::fail(CRN_ERR_ARG, "bad signal parameters");
+  if (sc->pu_model < CRN_PU_UNIFORM || sc->pu_model > CRN_PU_MARKOV_INTENDED)
+    return crn::fail(CRN_ERR_ARG, "unknown pu_model");
+  if (sc->signal_kind < CRN_SIG_TONES || sc->signal_kind > CRN_SIG_BAND_NOISE)
+    return crn::fail(CRN_ERR_ARG, "unknown signal_kind");
+  if (sc->n_streams < 1) return crn::fail(CRN_ERR_ARG, "n_streams must be >= 1");
+  if (sc->pu_model != CRN_PU_UNIFORM) {
+    if (!d_truth) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need d_truth");
+    if (n_epochs % sc->n_streams != 0) return crn::fail(CRN_ERR_ARG, "n_streams must divide n_epochs");
+  }
   const crn_cfg &c = h->cfg;
   crn::SynthParams p{};
   p.iq = reinterpret_cast<float2 *>(d_iq);
   p.n_epochs = n_epochs;
   p.samples_per_epoch = samples_per_epoch;
-  p.seed = seed;
-  p.noise_sigma = std::sqrt(noise_power * 0.5f);
-  p.tones = tones_per_band;
-  p.tone_amp = tones_per_band > 0 ? signal_rms / std::sqrt((float)tones_per_band) : 0.f;
+  p.seed = sc->seed;
+  p.noise_sigma = std::sqrt(sc->noise_power * 0.5f);
+  p.tones = sc->tones_per_band;
+  p.tone_amp = sc->tones_per_band > 0 ? sc->signal_rms / std::sqrt((float)sc->tones_per_band) : 0.f;
+  p.signal_rms = sc->signal_rms;
+  p.pu_model = sc->pu_model;
+  p.signal_kind = sc->signal_kind;
+  p.epochs_per_stream = n_epochs / sc->n_streams;
   p.fft_len = c.fft_len;
   if (c.ref_band >= 0 || c.decide == CRN_DECIDE_ANN) {  // {NF, CH1, ..}: band 0 is never driven
     p.active_band0 = 1;
@@ -432,10 +458,14 @@ int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs, int64_t 
     p.active_band0 = 0;
     p.n_active = c.n_bands;
   }
-  if (tones_per_band == 0) p.n_active = 0;
+  if (sc->signal_kind == CRN_SIG_TONES && sc->tones_per_band == 0) p.n_active = 0;
   p.band_bins_begin = h->d_band_bins_begin;
   p.band_bins = h->d_band_bins;
   p.truth = d_truth;
+  if (sc->pu_model != CRN_PU_UNIFORM) {
+    if (p.n_active < 1) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need at least one driven band");
+    HIP_TRY(crn::launch_pu_pattern(p, static_cast<hipStream_t>(stream)));
+  }
   HIP_TRY(crn::launch_synth(p, static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }

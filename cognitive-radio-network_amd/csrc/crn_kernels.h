@@ -64,6 +64,10 @@ struct SynthParams {
   const int *band_bins_begin;  // [n_bands + 1]
   const int *band_bins;        // flattened bin lists per band
   int32_t *truth;              // [n_epochs] or null
+  int pu_model;                // crn_pu_model; the Markov models read truth[] (filled by launch_pu_pattern)
+  int signal_kind;             // crn_signal_kind
+  float signal_rms;
+  long long epochs_per_stream; // Markov models
 };
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
@@ -72,6 +76,7 @@ int sense_num_variants();
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
+hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 
 }  // namespace crn
 #endif

@@ -1420,27 +1420,67 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
     float re = r * cs, im = r * sn;
 
     const uint64_t he = mix64(p.seed * 0x9E3779B97F4A7C15ull + (uint64_t)e + 0x51ED27ull);
-    const int pick = (int)(he % (uint64_t)(p.n_active + 1));  // 0 = idle epoch
+    // uniform model: independent pick per epoch (0 = idle); Markov models: state written by pu_pattern_kernel
+    const int pick = p.pu_model == 0 ? (int)(he % (uint64_t)(p.n_active + 1)) : p.truth[e];
     if (pick > 0) {
       const int band = p.active_band0 + pick - 1;
       const int nb = p.band_bins_begin[band + 1] - p.band_bins_begin[band];
       const int *bins = p.band_bins + p.band_bins_begin[band];
-      const int nt = p.tones < nb ? p.tones : nb;
       const int nmod = (int)(n % p.fft_len);
+      int nt = p.tones < nb ? p.tones : nb;
+      float amp = p.tone_amp;
+      uint64_t hsig = he;
+      if (p.signal_kind == 1) {  // CW: one carrier at the band centre
+        nt = 1;
+        amp = p.signal_rms;
+      } else if (p.signal_kind == 2) {  // every bin, new phases each frame
+        nt = nb;
+        amp = p.signal_rms * rsqrtf((float)nb);
+        hsig = mix64(he ^ (0xF00Dull + (uint64_t)(n / p.fft_len)));
+      }
       for (int j = 0; j < nt; j++) {
-        const int k = bins[(int)(((long long)(2 * j + 1) * nb) / (2 * nt))];
-        const uint64_t hp = mix64(he + 0x1234567ull * (uint64_t)(j + 1));
+        const int k = p.signal_kind == 2 ? bins[j] : bins[(int)(((long long)(2 * j + 1) * nb) / (2 * nt))];
+        const uint64_t hp = mix64(hsig + 0x1234567ull * (uint64_t)(j + 1));
         const float phase2 = (float)(uint32_t)(hp >> 40) * (2.0f / 16777216.0f);  // in units of pi
         const int kn = (int)(((long long)k * nmod) % p.fft_len);
         float s, c;
         sincospif(2.0f * (float)kn / (float)p.fft_len + phase2, &s, &c);
-        re = fmaf(p.tone_amp, c, re);
-        im = fmaf(p.tone_amp, s, im);
+        re = fmaf(amp, c, re);
+        im = fmaf(amp, s, im);
       }
     }
     p.iq[i] = make_float2(re, im);
-    if (n == 0 && p.truth != nullptr) p.truth[e] = pick;
+    if (n == 0 && p.truth != nullptr && p.pu_model == 0) p.truth[e] = pick;
   }
+}
+
+// Markov traffic models (include/crn_sense.h, crn_pu_model): one thread walks one stream's chain.
+// States 1..3 = CH1..CH3; the outcome of step j of stream s is a counter hash mod 10, standing in
+// for the reference's rand() % 10 (CE_PU_MARKOV_Chain_Tx.cpp:82-86).
+__global__ __launch_bounds__(64) void pu_pattern_kernel(const SynthParams p) {
+  const long long n_streams = p.n_epochs / p.epochs_per_stream;
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  int state = 1;
+  for (long long j = 0; j < p.epochs_per_stream; j++) {
+    const int outcome = (int)(mix64(p.seed ^ mix64(0xA5A5A5A5ull + (uint64_t)s * 0x100000001B3ull + (uint64_t)j)) % 10ull);
+    int next;
+    if (p.pu_model == 1) {  // as written: `>= 1 || < 4` is always true
+      next = outcome == 0 ? 1 : 2;
+    } else {                // as intended
+      const int stay2 = state == 2 ? 5 : 3;  // CH2 keeps outcomes 1..5, the others send 1..3 to CH2
+      next = outcome == 0 ? 1 : outcome <= stay2 ? 2 : 3;
+    }
+    state = next > p.n_active ? p.n_active : next;  // plans with fewer than three driven bands
+    p.truth[s * p.epochs_per_stream + j] = state;
+  }
+}
+
+hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream) {
+  if (p.n_epochs <= 0 || p.epochs_per_stream <= 0) return hipSuccess;
+  const long long n_streams = p.n_epochs / p.epochs_per_stream;
+  hipLaunchKernelGGL(pu_pattern_kernel, dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, stream, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream) {

@@ -233,6 +233,42 @@ CRN_API int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs,
                           float signal_rms, int32_t tones_per_band, int32_t *d_truth,
                           void *stream);
 
+/* Traffic models of the driven primary user (which band an epoch's signal occupies):
+ *  CRN_PU_UNIFORM           seeded uniform pick among {idle, band 1 .. band n_active}, independent per
+ *                           epoch — cognitive_engines/CE_Random_Behaviour_PU/CE_Random_Behaviour_PU.cpp:41-53
+ *                           (rand() % 3 over the channels) plus an idle state.
+ *  CRN_PU_MARKOV_AS_WRITTEN the chain of CE_PU_MARKOV_Chain_Tx.cpp:88-128 exactly as its conditions
+ *                           evaluate: outcome = rand() % 10; 0 -> CH1, anything else -> CH2 (the
+ *                           `>= 1 || < 4` tests are always true), CH3 unreachable, never idle.
+ *  CRN_PU_MARKOV_INTENDED   the same chain with the thresholds its comments intend (`&&`): from
+ *                           CH1/CH3: 0 -> CH1, 1..3 -> CH2, 4..9 -> CH3; from CH2: 0 -> CH1,
+ *                           1..5 -> CH2, 6..9 -> CH3.  Never idle.
+ * Markov models run per stream: the batch is n_streams consecutive runs of n_epochs / n_streams
+ * epochs, each an independent chain started in CH1 (d_truth is required). */
+typedef enum crn_pu_model { CRN_PU_UNIFORM = 0, CRN_PU_MARKOV_AS_WRITTEN = 1, CRN_PU_MARKOV_INTENDED = 2 } crn_pu_model;
+
+/* What the occupied band carries (src/interferer.cpp:128-140 CW / NOISE, :248-282 OFDM):
+ *  CRN_SIG_TONES      tones_per_band on-grid tones spread over the band, fixed random phases per epoch
+ *  CRN_SIG_CW         one carrier at the band's centre bin
+ *  CRN_SIG_BAND_NOISE every bin of the band, fresh random phases every fft_len samples (a
+ *                     frame-synchronous multicarrier burst: flat in-band spectrum) */
+typedef enum crn_signal_kind { CRN_SIG_TONES = 0, CRN_SIG_CW = 1, CRN_SIG_BAND_NOISE = 2 } crn_signal_kind;
+
+typedef struct crn_synth_cfg {
+  uint64_t seed;
+  float noise_power;      /* E|x|^2 of the complex AWGN */
+  float signal_rms;       /* RMS amplitude of the PU signal */
+  int32_t tones_per_band; /* CRN_SIG_TONES only */
+  int32_t pu_model;       /* crn_pu_model */
+  int32_t signal_kind;    /* crn_signal_kind */
+  int32_t n_streams;      /* >= 1; must divide n_epochs for the Markov models */
+} crn_synth_cfg;
+
+/* crn_synth_fill_device with a traffic model and a signal kind.  crn_synth_fill_device(.., seed,
+ * noise_power, signal_rms, tones, ..) == this with {CRN_PU_UNIFORM, CRN_SIG_TONES, n_streams 1}. */
+CRN_API int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq, int64_t n_epochs,
+                                     int64_t samples_per_epoch, int32_t *d_truth, void *stream);
+
 /* Name, registers and LDS of the sensing kernel selected for this handle. */
 CRN_API int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *threads_per_block,
                           int32_t *lds_bytes, int32_t *epochs_per_block);

@@ -30,6 +30,8 @@ def lib():
         L.crn_oracle_ref_weights.argtypes = [C.c_void_p, C.c_void_p]
         L.crn_oracle_run.argtypes = [C.POINTER(cs.Cfg), C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.POINTER(cs.Out), C.c_int32]
+        L.crn_oracle_synth.argtypes = [C.POINTER(cs.Cfg), C.POINTER(cs.SynthCfg), C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_void_p]
         _lib = L
     return _lib
 
@@ -93,3 +95,12 @@ def run(cfg, iq, n_epochs, L=None, want_spectrum=False, n_threads=1, epoch_strid
     rc = lib().crn_oracle_run(C.byref(cfg), iq.ctypes.data, n_epochs, L, epoch_stride, C.byref(o), n_threads)
     assert rc == 0, "crn_oracle_run rejected the configuration"
     return res
+
+
+def synth(cfg, sc, n_epochs, spe):
+    """CPU twin of crn_synth_fill_device_ex: returns (iq float32 [n_epochs * spe * 2], truth int32 [n_epochs])."""
+    iq = np.zeros(n_epochs * spe * 2, np.float32)
+    truth = np.zeros(n_epochs, np.int32)
+    rc = lib().crn_oracle_synth(C.byref(cfg), C.byref(sc), iq.ctypes.data, n_epochs, spe, truth.ctypes.data)
+    assert rc == 0, rc
+    return iq, truth

@@ -1,0 +1,150 @@
+"""Signal generator: the CPU twin's traffic models and signal kinds (no GPU), and
+the device generator against the twin sample by sample (gpu)."""
+import numpy as np
+import pytest
+
+import crnsense as cs
+import oracle_py as orc
+
+
+def _sc(seed=7, pu=cs.PU_UNIFORM, sig=cs.SIG_TONES, tones=8, n_streams=1, noise=1e-6, rms=0.02):
+    sc = cs.SynthCfg()
+    sc.seed, sc.noise_power, sc.signal_rms = seed, noise, rms
+    sc.tones_per_band, sc.pu_model, sc.signal_kind, sc.n_streams = tones, pu, sig, n_streams
+    return sc
+
+
+def test_markov_as_written_never_reaches_ch3(built):
+    """CE_PU_MARKOV_Chain_Tx.cpp:96-123: `>= 1 || < 4` is always true, so outcome 0 -> CH1 and every
+    other outcome -> CH2, whatever the state."""
+    cfg = cs.cfg_reference()
+    n_streams, eps = 8, 4000
+    _, truth = orc.synth(cfg, _sc(pu=cs.PU_MARKOV_AS_WRITTEN, n_streams=n_streams, noise=0.0, tones=1), n_streams * eps, 1)
+    assert set(truth.tolist()) == {1, 2}
+    assert abs((truth == 1).mean() - 0.1) < 0.01
+
+
+def test_markov_intended_stationary_distribution(built):
+    """P = [[.1,.3,.6],[.1,.5,.4],[.1,.3,.6]] -> stationary (0.1, 0.375, 0.525)."""
+    cfg = cs.cfg_reference()
+    n_streams, eps = 16, 8000
+    _, truth = orc.synth(cfg, _sc(pu=cs.PU_MARKOV_INTENDED, n_streams=n_streams, noise=0.0, tones=1), n_streams * eps, 1)
+    t = truth.reshape(n_streams, eps)
+    assert (t[:, 0] >= 1).all() and set(truth.tolist()) == {1, 2, 3}
+    freq = np.array([(truth == k).mean() for k in (1, 2, 3)])
+    assert np.abs(freq - np.array([0.1, 0.375, 0.525])).max() < 0.01
+    # transition rows
+    P = np.zeros((3, 3))
+    for a, b in zip(t[:, :-1].ravel(), t[:, 1:].ravel()):
+        P[a - 1, b - 1] += 1
+    P /= P.sum(axis=1, keepdims=True)
+    assert np.abs(P - np.array([[.1, .3, .6], [.1, .5, .4], [.1, .3, .6]])).max() < 0.02
+    # streams are independent chains
+    assert len({tuple(r[:64]) for r in t}) == n_streams
+
+
+def test_uniform_model_includes_idle(built):
+    cfg = cs.cfg_reference()
+    _, truth = orc.synth(cfg, _sc(noise=0.0, tones=1), 20000, 1)
+    freq = np.bincount(truth, minlength=4) / truth.size
+    assert np.abs(freq - 0.25).max() < 0.02
+
+
+@pytest.mark.parametrize("sig", [cs.SIG_TONES, cs.SIG_CW, cs.SIG_BAND_NOISE])
+def test_signal_kinds_land_in_their_band(built, sig):
+    """Spectrum of the noiseless signal: CW = one bin at the band centre, tones = tones_per_band bins,
+    band noise = every bin of the band at equal power; total power = signal_rms^2 in all three."""
+    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    spe = cs.samples_per_epoch(cfg)
+    n_epochs = 40
+    iq, truth = orc.synth(cfg, _sc(sig=sig, noise=0.0, tones=6, rms=0.5), n_epochs, spe)
+    x = iq.view(np.complex64).reshape(n_epochs, cfg.frames_per_epoch, cfg.fft_len)
+    for e in range(n_epochs):
+        P = (np.abs(np.fft.fft(x[e], axis=1)) ** 2).mean(axis=0) / cfg.fft_len ** 2
+        if truth[e] == 0:
+            assert P.sum() == 0
+            continue
+        bins = np.concatenate([np.arange(cfg.segs[s].lo, cfg.segs[s].hi) for s in range(cfg.n_segs)
+                               if cfg.segs[s].band == truth[e]])
+        inband = P[bins].sum()
+        assert abs(inband - 0.25) < 1e-3 and abs(P.sum() - inband) < 1e-6
+        lit = (P > 1e-9).sum()
+        assert lit == {cs.SIG_TONES: 6, cs.SIG_CW: 1, cs.SIG_BAND_NOISE: bins.size}[sig]
+        if sig == cs.SIG_BAND_NOISE:
+            assert np.allclose(P[bins], 0.25 / bins.size, rtol=1e-3)
+    assert len(set(truth.tolist())) == 4
+
+
+@pytest.mark.parametrize("pu", [cs.PU_UNIFORM, cs.PU_MARKOV_INTENDED])
+def test_oracle_decisions_follow_generated_traffic(built, pu):
+    """Reference-mode sensing of generated traffic: the cascade reports exactly the driven channel."""
+    cfg = cs.cfg_reference()
+    spe = cs.samples_per_epoch(cfg)
+    n = 96
+    iq, truth = orc.synth(cfg, _sc(pu=pu, n_streams=4), n, spe)
+    got = orc.run(cfg, iq, n)
+    assert np.array_equal(got["decision"], truth)
+
+
+def test_oracle_synth_rejects_bad_arguments(built):
+    import ctypes as C
+    cfg = cs.cfg_reference()
+    sc = _sc(pu=cs.PU_MARKOV_INTENDED, n_streams=5)
+    iq = np.zeros(12 * 2, np.float32)
+    truth = np.zeros(12, np.int32)
+    assert orc.lib().crn_oracle_synth(C.byref(cfg), C.byref(sc), iq.ctypes.data, 12, 1, truth.ctypes.data) == -1
+
+
+# ---- device generator against the twin ------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pu", [cs.PU_UNIFORM, cs.PU_MARKOV_AS_WRITTEN, cs.PU_MARKOV_INTENDED])
+@pytest.mark.parametrize("sig", [cs.SIG_TONES, cs.SIG_CW, cs.SIG_BAND_NOISE])
+@pytest.mark.parametrize("mode", ["ref512", "energy1024"])
+def test_device_generator_matches_twin(built, pu, sig, mode):
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = cs.cfg_reference() if mode == "ref512" else cs.cfg_energy_scaled(1024, 4.0)
+    spe = cs.samples_per_epoch(cfg)
+    n_streams, eps = 6, 11
+    n = n_streams * eps
+    sc = _sc(seed=1000 + 10 * pu + sig, pu=pu, sig=sig, n_streams=n_streams)
+    s = cs.Sensor(cfg)
+    iq = torch.zeros(n * spe * 2, dtype=torch.float32, device=dev)
+    truth = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    s.synth_fill_device_ex(iq.data_ptr(), n, spe, sc, truth_ptr=truth.data_ptr())
+    torch.cuda.synchronize()
+    want_iq, want_truth = orc.synth(cfg, sc, n, spe)
+    assert np.array_equal(truth.cpu().numpy(), want_truth)
+    scale = sc.signal_rms + np.sqrt(sc.noise_power)
+    assert np.abs(iq.cpu().numpy() - want_iq).max() < 1e-5 * scale
+    # and the sensing path on the generated samples reports the driven traffic
+    got = s.run_host(iq.cpu().numpy(), n)
+    if mode == "ref512":
+        # the shipped weights are calibrated for one signal shape and gain: only the
+        # multi-tone signal at its default level is expected to drive the cascade correctly
+        if sig == cs.SIG_TONES:
+            assert np.array_equal(got["decision"], want_truth)
+    else:
+        want_occ = np.zeros((n, cfg.n_bands), np.uint8)
+        idx = np.nonzero(want_truth > 0)[0]
+        want_occ[idx, want_truth[idx]] = 1
+        assert np.array_equal(got["occupancy"], want_occ)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_device_generator_argument_errors(built):
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = cs.cfg_reference()
+    s = cs.Sensor(cfg)
+    iq = torch.zeros(10 * 5120 * 2, dtype=torch.float32, device=dev)
+    truth = torch.zeros(10, dtype=torch.int32, device=dev)
+    with pytest.raises(cs.CrnError):   # Markov model without a truth buffer
+        s.synth_fill_device_ex(iq.data_ptr(), 10, 5120, _sc(pu=cs.PU_MARKOV_INTENDED))
+    with pytest.raises(cs.CrnError):   # streams must divide the epochs
+        s.synth_fill_device_ex(iq.data_ptr(), 10, 5120, _sc(pu=cs.PU_MARKOV_INTENDED, n_streams=3), truth_ptr=truth.data_ptr())
+    with pytest.raises(cs.CrnError):
+        s.synth_fill_device_ex(iq.data_ptr(), 10, 5120, _sc(sig=9), truth_ptr=truth.data_ptr())
+    s.close()
