@@ -23,7 +23,7 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
-    "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy",
     "crn_last_error", "crn_abi_version",
@@ -70,6 +70,11 @@ class SynthCfg(C.Structure):
                 ("n_streams", C.c_int32)]
 
 
+class TrainCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("iterations", C.c_int32), ("restarts", C.c_int32), ("eta", C.c_float),
+                ("alpha", C.c_float), ("normalise", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CrnError(RuntimeError):
     pass
 
@@ -99,6 +104,8 @@ def lib():
                                             C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
         L.crn_synth_fill_device_ex.argtypes = [C.c_void_p, C.POINTER(SynthCfg), C.c_void_p, C.c_int64, C.c_int64,
                                                C.c_void_p, C.c_void_p]
+        L.crn_ann_train_device.argtypes = [C.c_void_p, C.POINTER(TrainCfg), C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
         L.crn_sense_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
@@ -214,6 +221,29 @@ class Sensor:
         check(lib().crn_synth_fill_device_ex(self._h, C.byref(sc), iq_ptr, n_epochs, spe,
                                              C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
               "crn_synth_fill_device_ex")
+
+    def ann_train_device(self, tc, feat_ptr, label_ptr, n, stream=0):
+        """Fit the 4-5-3 network to device-resident features/labels; returns (w_ih, w_ho, loss)."""
+        import numpy as np
+        wih, who = np.zeros((5, 6), np.float64), np.zeros((6, 4), np.float64)
+        loss = C.c_double()
+        check(lib().crn_ann_train_device(self._h, C.byref(tc), feat_ptr, label_ptr, n, wih.ctypes.data,
+                                         who.ctypes.data, C.byref(loss), C.c_void_p(stream or None)),
+              "crn_ann_train_device")
+        return wih, who, loss.value
+
+
+def set_ann_weights(cfg, w_ih, w_ho, threshold=0.8):
+    """Put trained weights into a crn_cfg and select the ANN + cascade decision."""
+    for i in range(5):
+        for j in range(6):
+            cfg.ann_w_ih[i][j] = float(w_ih[i][j])
+    for j in range(6):
+        for k in range(4):
+            cfg.ann_w_ho[j][k] = float(w_ho[j][k])
+    cfg.ann_threshold = threshold
+    cfg.decide = DECIDE_ANN
+    return cfg
 
 
 class Ingest:

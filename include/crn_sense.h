@@ -219,6 +219,31 @@ CRN_API int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_re
 CRN_API int crn_ingest_drain(crn_ingest *g);
 CRN_API int crn_ingest_destroy(crn_ingest *g);
 
+/* -- training -------------------------------------------------------------
+ * The reference ships weights for one FFT size and one receiver gain (CE_Predictive_Node.cpp:78-120)
+ * and no way to make others.  crn_ann_train_device fits the same 4-5-3 sigmoid network
+ * (CE_Predictive_Node.hpp:20-22,62-73) to labelled features that are already on the device — e.g.
+ * the `features` output of crn_sense_run_device over crn_synth_fill_device traffic with its d_truth —
+ * by full-batch backpropagation (squared error, momentum), `restarts` independent initialisations in
+ * parallel (one workgroup each), and returns the best in the reference's array layout, ready for
+ * crn_cfg.ann_w_ih / ann_w_ho.  With `normalise`, feature i is scaled by 1/mean_i during training and
+ * the gains are folded back into W_IH, so inference stays exactly the reference's forward pass. */
+typedef struct crn_train_cfg {
+  uint64_t seed;
+  int32_t iterations;  /* gradient steps */
+  int32_t restarts;    /* >= 1 */
+  float eta;           /* learning rate */
+  float alpha;         /* momentum */
+  int32_t normalise;   /* 0 / 1 */
+  int32_t reserved;
+} crn_train_cfg;
+
+/* d_features: [n][4] float32 in ANN input order {NOISE_FLOOR, CH1, CH2, CH3}; d_labels: [n] int32,
+ * 0 = no channel occupied, k = channel k.  w_ih / w_ho / final_loss are host pointers.  Blocking. */
+CRN_API int crn_ann_train_device(crn_handle *h, const crn_train_cfg *tc, const float *d_features,
+                                 const int32_t *d_labels, int64_t n, double w_ih[5][6], double w_ho[6][4],
+                                 double *final_loss, void *stream);
+
 /* -- measurement / test aids ------------------------------------------------------------- */
 
 /* Fill d_iq with n_epochs * samples_per_epoch seeded synthetic samples on the device:

@@ -32,6 +32,8 @@ def lib():
                                      C.POINTER(cs.Out), C.c_int32]
         L.crn_oracle_synth.argtypes = [C.POINTER(cs.Cfg), C.POINTER(cs.SynthCfg), C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_void_p]
+        L.crn_oracle_ann_train.argtypes = [C.POINTER(cs.TrainCfg), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -104,3 +106,15 @@ def synth(cfg, sc, n_epochs, spe):
     rc = lib().crn_oracle_synth(C.byref(cfg), C.byref(sc), iq.ctypes.data, n_epochs, spe, truth.ctypes.data)
     assert rc == 0, rc
     return iq, truth
+
+
+def ann_train(tc, features, labels):
+    """CPU twin of crn_ann_train_device: returns (w_ih [5][6], w_ho [6][4], loss)."""
+    f = np.ascontiguousarray(features, dtype=np.float32)
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    wih, who = np.zeros((5, 6), np.float64), np.zeros((6, 4), np.float64)
+    loss = C.c_double()
+    rc = lib().crn_oracle_ann_train(C.byref(tc), f.ctypes.data, lab.ctypes.data, f.shape[0], wih.ctypes.data,
+                                    who.ctypes.data, C.byref(loss))
+    assert rc == 0, rc
+    return wih, who, loss.value

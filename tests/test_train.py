@@ -1,0 +1,179 @@
+"""Trainer for the reference's 4-5-3 network: the CPU twin on CPU; the device trainer
+against the twin, and the whole generate -> sense -> train -> decide loop on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import crnsense as cs
+import oracle_py as orc
+
+
+def _sc(seed, pu=cs.PU_UNIFORM, rms=0.02):
+    sc = cs.SynthCfg()
+    sc.seed, sc.noise_power, sc.signal_rms = seed, 1e-6, rms
+    sc.tones_per_band, sc.pu_model, sc.signal_kind, sc.n_streams = 8, pu, cs.SIG_TONES, 1
+    return sc
+
+
+def _tc(iterations=300, restarts=2, eta=2.0, alpha=0.9, normalise=1, seed=1):
+    tc = cs.TrainCfg()
+    tc.seed, tc.iterations, tc.restarts, tc.eta, tc.alpha, tc.normalise = seed, iterations, restarts, eta, alpha, normalise
+    return tc
+
+
+def _ref_mode_cfg(n, decide=cs.DECIDE_NONE):
+    """The reference's feature definition (|X| mean, square of sum) on the N-point scaled band plan."""
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    cfg.mode, cfg.decide = cs.MODE_REF_MAG, decide
+    return cfg
+
+
+def test_twin_learns_the_1024_point_features(built):
+    """The shipped weights are calibrated for N = 512 at one gain; at N = 1024 the features are ~4-8x
+    larger and a network has to be fitted.  Train on 768 generated epochs, decide 256 fresh ones."""
+    cfg = _ref_mode_cfg(1024)
+    spe = cs.samples_per_epoch(cfg)
+    iq, truth = orc.synth(cfg, _sc(5), 768, spe)
+    feat = orc.run(cfg, iq, 768, n_threads=4)["features"]
+    wih, who, loss = orc.ann_train(_tc(), feat, truth)
+    assert loss < 1e-3
+    assert (wih[:, 0] == 0).all() and (who[:, 0] == 0).all()  # column 0 is never read (.hpp:66,71)
+    iq2, truth2 = orc.synth(cfg, _sc(99), 256, spe)
+    got = orc.run(cs.set_ann_weights(_ref_mode_cfg(1024), wih, who), iq2, 256, n_threads=4)
+    assert np.array_equal(got["decision"], truth2)
+    assert np.abs(got["ann_out"] - 0.8).min() > 0.1  # decisive, not marginal
+
+
+def test_twin_normalisation_is_folded_into_the_weights(built):
+    """Training on features scaled by c with `normalise` gives W_IH rows scaled by 1/c and the same
+    network function: inference needs no separate normalisation step."""
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 4, 600).astype(np.int32)
+    feat = rng.uniform(0.5, 1.5, (600, 4)).astype(np.float32)
+    for k in (1, 2, 3):
+        feat[lab == k, k] *= 400.0
+    w1, h1, l1 = orc.ann_train(_tc(iterations=150, restarts=1), feat, lab)
+    w2, h2, l2 = orc.ann_train(_tc(iterations=150, restarts=1), feat * np.float32(64.0), lab)
+    assert np.allclose(w2[1:], w1[1:] / 64.0, rtol=1e-5, atol=0) and np.allclose(w2[0], w1[0], rtol=1e-5)
+    assert np.allclose(h1, h2, rtol=1e-5) and abs(l1 - l2) < 1e-6 * l1
+
+
+def test_twin_rejects_bad_arguments(built):
+    tc = _tc(restarts=0)
+    f = np.zeros((4, 4), np.float32)
+    lab = np.zeros(4, np.int32)
+    w, h = np.zeros((5, 6)), np.zeros((6, 4))
+    assert orc.lib().crn_oracle_ann_train(C.byref(tc), f.ctypes.data, lab.ctypes.data, 4, w.ctypes.data,
+                                          h.ctypes.data, None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalise,n", [(1, 3000), (0, 700)])
+def test_device_trainer_matches_twin(built, normalise, n):
+    """Same features, same order of arithmetic: weights to 1e-6, loss to 1e-8 relative."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11 + n)
+    lab = rng.integers(0, 4, n).astype(np.int32)
+    feat = rng.uniform(0.5, 1.5, (n, 4)).astype(np.float32)
+    for k in (1, 2, 3):
+        feat[lab == k, k] *= 50.0
+    if not normalise:
+        feat /= 50.0
+    tc = _tc(iterations=200, restarts=3, normalise=normalise, seed=77)
+    s = cs.Sensor(cs.cfg_reference())
+    d_feat = torch.from_numpy(feat).to(dev)
+    d_lab = torch.from_numpy(lab).to(dev)
+    import time
+    s.ann_train_device(tc, d_feat.data_ptr(), d_lab.data_ptr(), n)  # warm-up (module load)
+    t0 = time.perf_counter()
+    wih, who, loss = s.ann_train_device(tc, d_feat.data_ptr(), d_lab.data_ptr(), n)
+    t_gpu = time.perf_counter() - t0
+    s.close()
+    t0 = time.perf_counter()
+    twih, twho, tloss = orc.ann_train(tc, feat, lab)
+    t_cpu = time.perf_counter() - t0
+    print(f"trainer n={n} restarts={tc.restarts} iterations={tc.iterations}: device {t_gpu * 1e3:.1f} ms, "
+          f"CPU twin (1 thread) {t_cpu * 1e3:.1f} ms")
+    assert abs(loss - tloss) <= 1e-8 * tloss
+    assert np.allclose(wih, twih, rtol=1e-6, atol=1e-9) and np.allclose(who, twho, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,rms", [(1024, 0.02), (4096, 0.02), (512, 0.002), (4096, 0.001)])
+def test_generate_sense_train_decide_on_device(built, n_fft, rms):
+    """The loop the trainer exists for, device-resident end to end: generated traffic -> reference-mode
+    features from the sensing kernel -> fitted weights -> a handle whose fused ANN + cascade decides
+    fresh traffic (other seed, Markov model) without a single wrong epoch.  The shipped weights are
+    gain-specific (CE_Predictive_Node.cpp:78-120 were fitted at one receiver gain): at the default
+    signal level they still decide correctly, 20 dB lower they do not, a fitted network does."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = _ref_mode_cfg(n_fft)
+    spe = cs.samples_per_epoch(cfg)
+    n_train, n_test = 4096, 2048
+    s = cs.Sensor(cfg)
+    iq = torch.zeros(n_train * spe * 2, dtype=torch.float32, device=dev)
+    truth = torch.zeros(n_train, dtype=torch.int32, device=dev)
+    feat = torch.zeros(n_train, 4, dtype=torch.float32, device=dev)
+    s.synth_fill_device_ex(iq.data_ptr(), n_train, spe, _sc(2024, rms=rms), truth_ptr=truth.data_ptr())
+    s.run_device(iq.data_ptr(), n_train, n_fft, {"features": feat.data_ptr(), "ann_out": 0, "decision": 0,
+                                                "occupancy": 0, "spectrum": 0})
+    wih, who, loss = s.ann_train_device(_tc(iterations=400, restarts=4), feat.data_ptr(), truth.data_ptr(), n_train)
+    assert loss < 1e-3
+    s.close()
+
+    # the shipped N = 512 weights do not transfer to this size
+    shipped = cs.cfg_reference()
+    stale = _ref_mode_cfg(n_fft, cs.DECIDE_ANN)
+    for i in range(5):
+        for j in range(6):
+            stale.ann_w_ih[i][j] = shipped.ann_w_ih[i][j]
+    for j in range(6):
+        for k in range(4):
+            stale.ann_w_ho[j][k] = shipped.ann_w_ho[j][k]
+    stale.ann_threshold = 0.8
+
+    fitted = cs.set_ann_weights(_ref_mode_cfg(n_fft), wih, who)
+    iq2 = iq[: n_test * spe * 2]
+    truth2 = torch.zeros(n_test, dtype=torch.int32, device=dev)
+    dec = torch.zeros(n_test, dtype=torch.int32, device=dev)
+    ann = torch.zeros(n_test, 3, dtype=torch.float64, device=dev)
+    outs = {"features": 0, "ann_out": ann.data_ptr(), "decision": dec.data_ptr(), "occupancy": 0, "spectrum": 0}
+    acc = {}
+    for name, c in (("fitted", fitted), ("shipped", stale)):
+        sn = cs.Sensor(c)
+        sc = _sc(777, cs.PU_MARKOV_INTENDED, rms=rms)
+        sc.n_streams = 16
+        sn.synth_fill_device_ex(iq2.data_ptr(), n_test, spe, sc, truth_ptr=truth2.data_ptr())
+        sn.run_device(iq2.data_ptr(), n_test, n_fft, outs)
+        torch.cuda.synchronize()
+        acc[name] = float((dec == truth2).double().mean().item())
+        if name == "fitted":
+            assert float((ann - 0.8).abs().min().item()) > 0.05
+        sn.close()
+    print(f"N={n_fft} rms={rms}: fitted {acc['fitted']:.4f}  shipped {acc['shipped']:.4f}  loss {loss:.2e}")
+    assert acc["fitted"] == 1.0
+    if rms < 0.01:
+        assert acc["shipped"] < 1.0
+
+
+@pytest.mark.gpu
+def test_device_trainer_argument_errors(built):
+    import torch
+    dev = torch.device("cuda", 0)
+    s = cs.Sensor(cs.cfg_reference())
+    f = torch.zeros(8, 4, dtype=torch.float32, device=dev)
+    lab = torch.zeros(8, dtype=torch.int32, device=dev)
+    with pytest.raises(cs.CrnError):
+        s.ann_train_device(_tc(restarts=0), f.data_ptr(), lab.data_ptr(), 8)
+    with pytest.raises(cs.CrnError):
+        s.ann_train_device(_tc(alpha=1.5), f.data_ptr(), lab.data_ptr(), 8)
+    with pytest.raises(cs.CrnError):
+        s.ann_train_device(_tc(), f.data_ptr(), lab.data_ptr(), 0)
+    s.close()
+    w = cs.Sensor(cs.cfg_welch(1024, 4, 64))   # 64 bands: not the 4-feature network's input
+    with pytest.raises(cs.CrnError):
+        w.ann_train_device(_tc(), f.data_ptr(), lab.data_ptr(), 8)
+    w.close()
