@@ -269,10 +269,17 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
     crn::sense_variant(h->cfg.fft_len, h->cfg.mode == CRN_MODE_REF_MAG || h->cfg.window != CRN_WINDOW_RECT ? -1 : h->variant,
                        &nbuf, &pf, &nt, &tl, &pk);
     const bool plain4096 = h->cfg.fft_len == 4096 && h->cfg.mode != CRN_MODE_REF_MAG && h->cfg.window == CRN_WINDOW_RECT;
-    const bool pruned = plain4096 && (h->variant == 0 || h->variant == 13) && (h->row_mask & ~0x8267u) == 0;
-    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d%s>",
+    // what a launch without a spectrum output runs (a spectrum request falls back to full rows / the LDS close)
+    bool reg_close = h->n_row_entries > 0 && h->cfg.fft_len >= 1024 && h->cfg.window == CRN_WINDOW_RECT;
+    if (plain4096) {  // of the A/B set only these carry the register form
+      const int v = h->variant == 0 ? 13 : h->variant;
+      const bool rows_ok = (h->row_mask & ~0x8267u) == 0;
+      reg_close = reg_close && (v == 2 || v == 13 || v == 16 || v == 17 || v == 18 || (v == 7 && rows_ok));
+    }
+    const bool pruned = plain4096 && reg_close && (h->variant == 0 || h->variant == 13) && (h->row_mask & ~0x8267u) == 0;
+    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d,CLOSE=%s%s>",
                   h->cfg.fft_len / 256, nbuf, pf, nt, tl, pk,
-                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT,
+                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT, reg_close ? "registers" : "lds",
                   pruned ? ",PASS3_ROWS=0x8267(reference channel plan; full rows when a spectrum is requested)" : "");
   }
   return CRN_OK;
