@@ -150,6 +150,8 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     band_tab[256 + i] = seg_hi[i];
   }
   std::memcpy(&band_tab[416], cfg->thresh, sizeof(float) * CRN_MAX_BANDS);
+  std::memcpy(&band_tab[544], cfg->ann_w_ih, sizeof(cfg->ann_w_ih));  // 30 doubles
+  std::memcpy(&band_tab[604], cfg->ann_w_ho, sizeof(cfg->ann_w_ho));  // 24 doubles
   // Row entries for the register-resident band sums (epoch_close): every thread's accumulators sit
   // at bins base + 256 d, so a segment is cut at the 256-bin rows and each piece becomes
   // (row d, band, [lo, hi) inside the row), grouped by row, band-table order kept inside a row.

@@ -7,7 +7,7 @@
 
 namespace crn {
 
-constexpr int kBandTabWords = 544;   // SenseParams::band_tab, copied to LDS by every workgroup
+constexpr int kBandTabWords = 656;   // SenseParams::band_tab, copied to LDS by every workgroup
 constexpr int kRowEntryWords = 32;   // row-entry slots of the register-resident band sums: 32 / R3 per row
 
 enum { CRN_DECIDE_ANN_K = 0, CRN_DECIDE_THRESHOLD_K = 1, CRN_DECIDE_NONE_K = 2 };  // == crn_decide
@@ -29,7 +29,7 @@ struct SenseParams {
   const int *band_tab;        // [kBandTabWords] packed copy of the tables below, staged into LDS by every workgroup:
                               //   [0,96) band_seg_begin, [96,256) seg_lo, [256,416) seg_hi, [416,496) thresh (float bits),
                               //   [512,544) row entries band<<18 | lo<<9 | hi, 32 / R3 slots per 256-bin row, 0 = unused
-                              //   (only when n_row_entries > 0)
+                              //   (only when n_row_entries > 0), [544,604) ann_w_ih as 30 doubles, [604,652) ann_w_ho as 24 doubles
   const int *band_seg_begin;  // [n_bands + 1] into seg_lo/seg_hi (segments grouped by band)
   const int *seg_lo;
   const int *seg_hi;

@@ -646,12 +646,13 @@ CRN_DEV void frame_step(cx (&cur)[16], FrameCtx<C> &c, int f, const cx (&u0)[16]
 // bin order -> band sums -> features -> decision.  Resets the accumulators for the next epoch.
 // ---------------------------------------------------------------------------------------------
 // LDS behind the exchange buffers and the tw2 table, used by the epoch close: the band table copy,
-// then [8 teams][16] per-team band partials and [8 groups][16] features of the register path.
-constexpr int kCloseLdsBytes = kBandTabWords * 4 + 2 * 8 * 16 * 4;
+// then [8 teams][16] per-team band partials of the register path.
+constexpr int kCloseLdsBytes = kBandTabWords * 4 + 8 * 16 * 4;
 
 // LDS address-space views for the epoch close (see epoch_close): ds_* instructions, lgkmcnt only.
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) double lds_f64;
 CRN_DEV unsigned lds_offset(const void *p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
 }
@@ -713,41 +714,57 @@ CRN_DEV void s_wait_row(V &r) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
 }
 
-// The reference's 4-5-3 sigmoid network and cascade (CE_Predictive_Node.cpp:200-261) on one lane.
-CRN_DEV void ann_decide(const SenseParams &p, long long epoch, float nf, float ch1, float ch2, float ch3) {
+// The reference's 4-5-3 sigmoid network and cascade (CE_Predictive_Node.cpp:200-261), spread over the
+// lanes of a team: hidden unit j on lane j, output k on lane k, values passed with v_readlane.  Each
+// unit's sum is formed by one lane in the reference's order, so the results are those of the serial
+// loop; what changes is the latency — two exp() in sequence instead of eight (one lane doing all of
+// it cost the reference-mode kernel 3.8 %).  Weights come from the LDS copy of the table (a per-lane
+// global load would wait on vmcnt behind the prefetch).  Every lane of the team must call this.
+template <int TEAM>
+CRN_DEV double lane_f64(double v, int src, int half) {
+  const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), src);
+  double r = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  if constexpr (TEAM == 32) {  // two groups share a wave: the upper one reads lanes 32 + src
+    const int lo2 = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), 32 + src);
+    const int hi2 = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), 32 + src);
+    const double r2 = __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
+    r = half ? r2 : r;
+  }
+  return r;
+}
+
+template <int TEAM>
+CRN_DEV void ann_decide_team(const SenseParams &p, const lds_f64 *w_ih, const lds_f64 *w_ho, long long epoch,
+                             bool store, int lane, int half, float nf, float ch1, float ch2, float ch3) {
   // .cpp:200: Features_Buffer = {0, NOISE_FLOOR, CH1, CH2, CH3} widened to double
   const double f1 = (double)nf, f2 = (double)ch1, f3 = (double)ch2, f4 = (double)ch3;
+  const int j = (lane >= 1 && lane <= 5) ? lane : 1;  // .cpp:214-220, unit j
+  double s = w_ih[0 * 6 + j];
+  s += f1 * w_ih[1 * 6 + j];
+  s += f2 * w_ih[2 * 6 + j];
+  s += f3 * w_ih[3 * 6 + j];
+  s += f4 * w_ih[4 * 6 + j];
+  const double hj = 1.0 / (1.0 + exp(-s));
   double hid[6];
 #pragma unroll
-  for (int j = 1; j <= 5; j++) {  // .cpp:214-220
-    double s = p.ann_w_ih[0 * 6 + j];
-    s += f1 * p.ann_w_ih[1 * 6 + j];
-    s += f2 * p.ann_w_ih[2 * 6 + j];
-    s += f3 * p.ann_w_ih[3 * 6 + j];
-    s += f4 * p.ann_w_ih[4 * 6 + j];
-    hid[j] = 1.0 / (1.0 + exp(-s));
-  }
-  double o[4];
+  for (int q = 1; q <= 5; q++) hid[q] = lane_f64<TEAM>(hj, q, half);
+  const int k = (lane >= 1 && lane <= 3) ? lane : 1;  // .cpp:229-235, output k
+  double so = w_ho[0 * 4 + k];
 #pragma unroll
-  for (int k = 1; k <= 3; k++) {  // .cpp:229-235
-    double s = p.ann_w_ho[0 * 4 + k];
-#pragma unroll
-    for (int j = 1; j <= 5; j++) s += hid[j] * p.ann_w_ho[j * 4 + k];
-    o[k] = 1.0 / (1.0 + exp(-s));
-  }
+  for (int q = 1; q <= 5; q++) so += hid[q] * w_ho[q * 4 + k];
+  const double ok = 1.0 / (1.0 + exp(-so));
+  const double o1 = lane_f64<TEAM>(ok, 1, half), o2 = lane_f64<TEAM>(ok, 2, half), o3 = lane_f64<TEAM>(ok, 3, half);
   // .cpp:245-261 cascade
   int d = 0;
-  if (o[1] >= p.ann_threshold) d = 1;
-  else if (o[2] >= p.ann_threshold) d = 2;
-  else if (o[3] >= p.ann_threshold) d = 3;
-  if (p.ann_out != nullptr) {
-    p.ann_out[epoch * 3 + 0] = o[1];
-    p.ann_out[epoch * 3 + 1] = o[2];
-    p.ann_out[epoch * 3 + 2] = o[3];
+  if (o1 >= p.ann_threshold) d = 1;
+  else if (o2 >= p.ann_threshold) d = 2;
+  else if (o3 >= p.ann_threshold) d = 3;
+  if (store) {
+    if (lane >= 1 && lane <= 3 && p.ann_out != nullptr) p.ann_out[epoch * 3 + (lane - 1)] = ok;
+    if (lane == 0 && p.decision != nullptr) p.decision[epoch] = d;
+    if (lane < p.n_bands && p.occupancy != nullptr) p.occupancy[epoch * p.n_bands + lane] = (uint8_t)(lane >= 1 && lane == d);
   }
-  if (p.decision != nullptr) p.decision[epoch] = d;
-  if (p.occupancy != nullptr)
-    for (int b = 0; b < p.n_bands; b++) p.occupancy[epoch * p.n_bands + b] = (uint8_t)(b >= 1 && b == d);
 }
 
 template <class C>
@@ -804,6 +821,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * G::GROUP_CPLX * sizeof(cx));
   const lds_i32 *tab = reinterpret_cast<const lds_i32 *>(tab_off);
   const lds_f32 *thr = reinterpret_cast<const lds_f32 *>(tab_off + 416 * 4);
+  const lds_f64 *w_ih = reinterpret_cast<const lds_f64 *>(tab_off + 544 * 4);  // [5][6]
+  const lds_f64 *w_ho = reinterpret_cast<const lds_f64 *>(tab_off + 604 * 4);  // [6][4]
   lds_f32 *spec = reinterpret_cast<lds_f32 *>(gb_off);    // N + N/16 floats
   lds_f32 *featl = spec + spec_phys(N);                   // CRN_MAX_BANDS floats (LDS path)
   constexpr int TEAM = G::TEAM;
@@ -890,7 +909,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       const bool in = lane < p.n_bands;
       if (p.decide == CRN_DECIDE_ANN_K) {
         const float nf = from_lane(0), ch1 = from_lane(1), ch2 = from_lane(2), ch3 = from_lane(3);
-        if (active && t == 0) ann_decide(p, epoch, nf, ch1, ch2, ch3);
+        ann_decide_team<TEAM>(p, w_ih, w_ho, epoch, active, lane, half, nf, ch1, ch2, ch3);
       } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
         const float ref = p.ref_band >= 0 ? from_lane(p.ref_band) : 1.0f;
         const bool occ = active && in && f > thr_lane * ref;
@@ -968,7 +987,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
         for (int b = t; b < p.n_bands; b += TEAM) p.features[epoch * p.n_bands + b] = feat[b];
 
       if (p.decide == CRN_DECIDE_ANN_K) {
-        if (t == 0) ann_decide(p, epoch, feat[0], feat[1], feat[2], feat[3]);
+        ann_decide_team<TEAM>(p, w_ih, w_ho, epoch, true, lane, TEAM == 32 ? (tid & 32) : 0, feat[0], feat[1], feat[2], feat[3]);
       } else if (p.decide == CRN_DECIDE_THRESHOLD_K) {
         // lane i takes bands i, i + TEAM, ...; the count of occupied bands is a ballot, not a serial walk
         {
