@@ -272,7 +272,7 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
                        &nbuf, &pf, &nt, &tl, &pk);
     const bool plain4096 = h->cfg.fft_len == 4096 && h->cfg.mode != CRN_MODE_REF_MAG && h->cfg.window == CRN_WINDOW_RECT;
     // what a launch without a spectrum output runs (a spectrum request falls back to full rows / the LDS close)
-    bool reg_close = h->n_row_entries > 0 && h->cfg.fft_len >= 1024 && h->cfg.window == CRN_WINDOW_RECT;
+    bool reg_close = h->n_row_entries > 0 && h->cfg.window == CRN_WINDOW_RECT;
     if (plain4096) {  // of the A/B set only these carry the register form
       const int v = h->variant == 0 ? 13 : h->variant;
       const bool rows_ok = (h->row_mask & ~0x8267u) == 0;

@@ -1270,19 +1270,15 @@ static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.sp
 template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
-  // small band plan, no spectrum: band sums from registers.  Not at N = 512: 16 entry slots x 8 bins
-  // per thread and row unroll into a close that pushes frame-loop values to scratch (-3 %).
-  const bool regb = reg_bands(p);
+  const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
 #define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
   if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
   if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
-  if constexpr (R3 >= 4) {
-    if (regb) {
-      if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
-      if (full) CRN_GO_R(false, false, true);
-      CRN_GO_R(false, false, false);
-    }
+  if (regb) {
+    if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
+    if (full) CRN_GO_R(false, false, true);
+    CRN_GO_R(false, false, false);
   }
   if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
   if (full) CRN_GO(false, false, true);
