@@ -1,4 +1,4 @@
-// engine_harness.cpp — offline driver: plays the rx worker + CE worker of the ECR
+// engine_harness.cpp — TEST INFRASTRUCTURE.  Offline driver: plays the rx worker + CE worker of the ECR
 // (reference: src/extensible_cognitive_radio.cpp:1310-1324 hand-off, :1792-1803 dispatch) against
 // CE_Predictive_Node_GPU, feeding packets from a binary file of interleaved fp32 IQ.
 //

@@ -4,7 +4,7 @@ test suite; used to hunt rare codegen / aliasing bugs with spare GPU minutes).""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd"), os.path.join(ROOT, "tests")]  # run as: python tests/soak_gpu.py [n]
 import crnsense as cs, oracle_py as orc, signals
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200

@@ -223,7 +223,7 @@ def test_engine_drop_in_matches_reference_epoch(built, binary, mode, tmp_path):
     reference's own CognitiveEngine object code (built where /root/reference is mounted)."""
     import os
     import subprocess
-    exe = os.path.join(os.path.dirname(cs.LIB_PATH), "host", binary)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", binary)
     if not os.path.exists(exe):
         pytest.skip(f"{binary} was not built (reference tree absent at build time)")
     cfg = cs.cfg_reference()
