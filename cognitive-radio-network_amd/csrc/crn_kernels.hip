@@ -16,7 +16,8 @@
 //   one s_barrier per frame (two with a single LDS buffer) and N <= 1024 needs none.
 //   HBM is read exactly once: 8 B per input sample, coalesced 512 B per wave instruction.
 //   |X|^2 (or |X|) is accumulated per bin in 16 registers per thread over the K frames; the band
-//   reduction, the net and the cascade run once per epoch from LDS.
+//   reduction, the net and the cascade run once per epoch (epoch_close: from the registers for small
+//   band plans, through an LDS image of the spectrum otherwise).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -36,7 +37,7 @@ typedef float cx __attribute__((ext_vector_type(2)));
 // PK = true: one VOP3P instruction per complex add / rotate-add and two per complex multiply,
 // with the re/im swaps and sign flips expressed through op_sel / neg modifiers, so no v_mov is
 // spent on shuffling.  A lone wave issues one VALU instruction every ~4.6 cycles on gfx950
-// whether it is packed or not (measured, tools/valu_rate.hip), so at the 2-3 waves per SIMD this
+// whether it is packed or not (measured, tools/valu_rate.hip), so at the 3-4 waves per SIMD this
 // kernel runs at, halving the instruction count is what shortens a frame.
 // PK = false: plain scalar fp32 (reference build of the same arithmetic, used for A/B).
 // Operand semantics (VOP3P, 64-bit sources): op_sel[i] picks the half of source i feeding the
@@ -297,7 +298,8 @@ CRN_DEV void wave_sync() {
 //   WIN      multiply by the window table
 //   TW2LDS   pass-2 twiddles read from an LDS table instead of 30 registers
 //   OCC      workgroups per CU the register allocation must allow
-//   ABL      measurement ablations: 0 none; 1 stream only (no FFT); 2 compute only (no re-load)
+//   ABL      measurement ablations: 0 none; 1 stream only (no FFT); 2 compute only (no re-load);
+//            3 butterflies only (no re-load, no LDS exchange)
 //   FULL     every frame brings all N samples (L == N): no zero-padding mask
 //   PK       packed-f32 butterflies (see M<PK>)
 // ---------------------------------------------------------------------------------------------
@@ -312,15 +314,14 @@ enum : int {
   kMulti = 512,  // a workgroup streams through several consecutive epoch groups
   kPrioValu = 1024, // s_setprio 1 through the butterflies of passes 1 and 2 (where the prefetch loads issue)
   kNoClose = 2048,  // measurement ablation: the epoch close only folds and resets the accumulators
-  kRegBands = 8192, // epoch close forms the band sums from registers (plans with n_row_entries > 0, no spectrum)
   kTrace = 4096,    // measurement aid: s_memtime at epoch-close entry / exit into the ann_out buffer
-
+  kRegBands = 8192, // epoch close forms the band sums from registers (plans with n_row_entries > 0, no spectrum)
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
           bool FULL_, bool PK_, int OPT_ = 0>
 struct Cfg {
-  static constexpr int OPT = OPT_;  // kPair | kSpread | kLdsBlk | kTw1C | kFence | kRows
+  static constexpr int OPT = OPT_;  // OR of the flags above
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
