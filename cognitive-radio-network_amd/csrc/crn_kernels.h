@@ -22,6 +22,8 @@ struct SenseParams {
   int L;                   // samples taken per frame (zero-padded to N)
   int K;                   // frames per epoch
   int groups_per_wg;       // consecutive epoch groups one workgroup streams through (>= 1)
+  long long n_big_wgs;     // workgroups [0, n_big_wgs) take groups_per_wg groups each; the ones after them one
+                           // group each (they are dispatched last: the end of the kernel drains in small steps)
   // tables (device, built at crn_sense_create)
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}

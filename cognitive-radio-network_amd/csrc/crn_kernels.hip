@@ -805,10 +805,13 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     // [epoch][3] uint64: entry of the group's first wave; its later stamps as four 16-bit deltas
     // (band sums done, barrier passed, features ready, exit); entry of the group's last wave
     unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
+    // entries in s_memrealtime (100 MHz, the same clock on every XCD: comparable across workgroups);
+    // the deltas inside the block in s_memtime (shader clock, finer, per-XCD)
+    const unsigned long long wall = __builtin_amdgcn_s_memrealtime();
     tr0 = __builtin_amdgcn_s_memtime();
     if (active && tr != nullptr) {
-      if (t == 0) tr[epoch * 3 + 0] = tr0;
-      if (t == T - 1) tr[epoch * 3 + 2] = tr0;
+      if (t == 0) tr[epoch * 3 + 0] = wall;
+      if (t == T - 1) tr[epoch * 3 + 2] = wall;
     }
   }
   // Energy mode: the division by K is applied to the band sums (and to the per-bin values only
@@ -1187,9 +1190,15 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       // flight while the last frame of this one is computed and closed (the per-workgroup prologue
       // and the exposed first load cost ~6 % at one epoch per workgroup).  Two register sets in
       // ping-pong; frame f+1's loads are issued from inside frame f's butterflies.
-      const int epw = p.groups_per_wg;
+      // Workgroups are dispatched in blockIdx order; the last ones take a single epoch group, so the
+      // machine drains in steps of one epoch instead of one 4-epoch workgroup (measured with
+      // s_memrealtime stamps: the last 1024 workgroups used to finish spread over 200 us of a
+      // 1.4 ms kernel).
       const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
-      const long long g0 = (long long)blockIdx.x * epw;
+      const bool big = (long long)blockIdx.x < p.n_big_wgs;
+      const int epw = big ? p.groups_per_wg : 1;
+      const long long g0 = big ? (long long)blockIdx.x * p.groups_per_wg
+                               : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs);
       const int n_local = (int)((n_groups - g0) < epw ? (n_groups - g0) : epw);
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, g0, epw);
       const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * 8u;
@@ -1249,8 +1258,16 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
   const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
                      !(C::WIN && p.frame_stride * 2 == G::N);
-  const int epw = multi ? p.groups_per_wg : 1;
-  const unsigned grid = (unsigned)((n_groups + epw - 1) / epw);
+  SenseParams q = p;
+  unsigned grid;
+  if (multi) {
+    // n_big_wgs workgroups of groups_per_wg groups, then one workgroup per remaining group
+    if (q.n_big_wgs * q.groups_per_wg > n_groups) q.n_big_wgs = n_groups / q.groups_per_wg;
+    grid = (unsigned)(q.n_big_wgs + (n_groups - q.n_big_wgs * q.groups_per_wg));
+  } else {
+    q.n_big_wgs = 0;
+    grid = (unsigned)n_groups;
+  }
   const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
@@ -1259,7 +1276,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, q);
   return hipGetLastError();
 }
 

@@ -502,3 +502,21 @@ def test_streaming_workgroups_over_several_epoch_groups(built, n, n_epochs, epw)
         if K == 3:
             truth = signals.spectrum_f64(cfg, iq, n_epochs)
             assert per_bin_err(got["spectrum"], truth, 1e-1) < PER_BIN_TOL
+
+
+@pytest.mark.parametrize("n,n_epochs,epw,tail", [(4096, 41, 4, 0), (4096, 41, 4, 256), (1024, 203, 3, 256), (512, 333, 4, 0)])
+def test_graded_workgroups_cover_every_epoch_once(built, n, n_epochs, epw, tail):
+    """Launch geometry: `n_big` workgroups of `epw` epoch groups, then one workgroup per remaining
+    group (they are dispatched last, so the kernel drains in single-epoch steps).  Whatever the mix
+    (tail capped at a quarter of the groups; none), every epoch is computed exactly once."""
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    iq, picks = signals.make_epochs(cfg, n_epochs, seed=7 * n + tail)
+    s = cs.Sensor(cfg)
+    s.set_variant(100 + epw)
+    s.set_variant(200 + tail // 256)
+    got = s.run_host(iq, n_epochs)
+    s.close()
+    want = orc.run(cfg, iq, n_epochs)
+    assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
+    assert np.array_equal(got["occupancy"], want["occupancy"])
+    assert np.array_equal(got["decision"], want["decision"])

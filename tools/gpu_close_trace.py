@@ -31,9 +31,23 @@ for name, x in (("band sums done", d[0]), ("barrier passed", d[1]), ("features r
 dur = d[3]
 skew = enter3 - enter0
 print("close duration of the first wave [memtime ticks]: median %d  p10 %d  p90 %d  mean %.0f" % (np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), dur.mean()))
-print("entry skew last wave - first wave: median %d  p10 %d  p90 %d" % (np.median(skew), np.percentile(skew, 10), np.percentile(skew, 90)))
+print("entry skew last wave - first wave [10 ns]: median %d  p10 %d  p90 %d" % (np.median(skew), np.percentile(skew, 10), np.percentile(skew, 90)))
 # epochs 4g..4g+3 belong to one workgroup (groups_per_wg = 4): time between consecutive closes
 e = enter0.reshape(-1, 4)
 gap = (e[:, 1:] - e[:, :-1]).ravel()
-print("entry-to-entry of consecutive epochs in a workgroup (10 frames + close): median %d  p10 %d p90 %d" % (np.median(gap), np.percentile(gap, 10), np.percentile(gap, 90)))
+print("entry-to-entry of consecutive epochs in a workgroup (10 frames + close) [10 ns]: median %d  p10 %d p90 %d" % (np.median(gap), np.percentile(gap, 10), np.percentile(gap, 90)))
 print("whole kernel span in ticks: %d" % (a[:, 0].max() - a[:, 0].min()))
+
+# workgroup occupancy of the machine: a workgroup (4 consecutive epochs) is busy from about one epoch
+# before its first close to its last close; 1024 workgroup slots (256 CUs x 4)
+first, last = e[:, 0], e[:, 3]
+per_epoch = (e[:, 3] - e[:, 0]) / 3.0
+start = first - per_epoch
+span = last.max() - start.min()
+busy = (last - start).sum()
+print("workgroups %d, span %.1f us, slot utilisation %.3f" % (e.shape[0], span / 100.0, busy / (1024.0 * span)))
+order = np.sort(last)
+print("finish times of the last 1024 workgroups relative to the end [10 ns]: p50 %d  p10 %d  min %d" % (
+    np.median(order[-1024:]) - order[-1], np.percentile(order[-1024:], 10) - order[-1], order[-1024] - order[-1]))
+print("start times of the first 1024 workgroups relative to the start [10 ns]: p50 %d  p90 %d  max %d" % (
+    np.median(np.sort(start)[:1024]) - start.min(), np.percentile(np.sort(start)[:1024], 90) - start.min(), np.sort(start)[1023] - start.min()))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Sweep groups_per_wg (epoch groups streamed by one workgroup) for the headline kernel on one box.
-Usage: python tools/gpu_epw.py [fft] ; prints kernel ms per setting, interleaved repetitions."""
+"""Sweep the number of epoch groups handed to single-group workgroups at the end of the launch
+(crn_sense_set_variant 200 + n = n x 256 groups).  Interleaved repetitions on one box."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cognitive-radio-network_amd"))
 import torch
@@ -25,8 +25,8 @@ for _ in range(60):
 torch.cuda.synchronize()
 res = {}
 for rep in range(3):
-    for epw in (0, 2, 4, 7, 8, 14, 28, 56):
-        s.set_variant(100 + epw)
+    for n in (0, 2, 4, 8, 12, 16, 24, 32):
+        s.set_variant(200 + n)
         for _ in range(5):
             s.run_device(iq.data_ptr(), E, fft, outs, stream=stream)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,6 +35,6 @@ for rep in range(3):
             s.run_device(iq.data_ptr(), E, fft, outs, stream=stream)
         b.record()
         torch.cuda.synchronize()
-        res.setdefault(epw, []).append(a.elapsed_time(b) / 40)
-for epw, v in res.items():
-    print(f"N={fft} groups_per_wg={epw}: " + " ".join(f"{x:.4f}" for x in v) + f"  frac={E*spe*8/(min(v)*1e-3)/8e12:.4f}")
+        res.setdefault(n, []).append(a.elapsed_time(b) / 40)
+for n, v in res.items():
+    print(f"N={fft} tail groups={n * 256:5d}: " + " ".join(f"{x:.4f}" for x in v) + f"  frac={E*spe*8/(min(v)*1e-3)/8e12:.4f}")
