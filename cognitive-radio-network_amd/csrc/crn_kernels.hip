@@ -956,28 +956,56 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     }
 
     // band sums (reference .cpp:173-191), one team of lanes per band.  This stretch is pure latency
-    // (the wave has no loads in flight beyond its prefetched frame), so: table walk from LDS, four
-    // independent bin reads per trip, DPP/readlane reduction instead of ds_bpermute shuffles.
+    // (the wave has no loads in flight beyond its prefetched frame) and an LDS round trip queues behind
+    // the CU's exchange traffic, so the table walk is taken off the per-band path: lane i of a team
+    // fetches the descriptor (segment range, first segment's bins) of the team's i-th band — all
+    // lanes at once, two round trips per TEAM bands instead of two per band — and the band loop picks
+    // them up with v_readlane.  Then four independent bin reads per trip and the DPP/readlane
+    // reduction.  Bands with more than one segment walk the rest of the table as before.
     {
       const int team = t / TEAM;
-      for (int b = team; b < p.n_bands; b += TPG) {
-        float s = 0.f;
-        const int s0 = tab[b], s1 = tab[b + 1];
-        for (int sg = s0; sg < s1; sg++) {
-          const int lo = tab[96 + sg], hi = tab[256 + sg];
-          for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
-            float v[4];
+      const int half = TEAM == 32 ? (tid & 32) : 0;
+      auto pick = [&](int v, int i) {  // lane i of this team -> every lane (i uniform)
+        const int a0 = __builtin_amdgcn_readlane(v, i);
+        if constexpr (TEAM == 32) {
+          const int a1 = __builtin_amdgcn_readlane(v, 32 + i);
+          return half ? a1 : a0;
+        }
+        return a0;
+      };
+      auto add_bins = [&](float &s, int lo, int hi) {
+        for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
+          float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const int k = k0 + i * TEAM;
-              const float x = spec[spec_phys(k < hi ? k : lo)];
-              v[i] = k < hi ? x : 0.f;
-            }
-            s += (v[0] + v[1]) + (v[2] + v[3]);
+          for (int i = 0; i < 4; i++) {
+            const int k = k0 + i * TEAM;
+            const float x = spec[spec_phys(k < hi ? k : lo)];
+            v[i] = k < hi ? x : 0.f;
+          }
+          s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      };
+      for (int c0 = 0; c0 < p.n_bands; c0 += TEAM * TPG) {  // TEAM bands per team and chunk
+        const int mine = c0 + lane * TPG + team;            // the band whose descriptor this lane fetches
+        int d_s0 = 0, d_s1 = 0, d_lo = 0, d_hi = 0;
+        if (mine < p.n_bands) {
+          d_s0 = tab[mine];
+          d_s1 = tab[mine + 1];
+          if (d_s1 > d_s0) {
+            d_lo = tab[96 + d_s0];
+            d_hi = tab[256 + d_s0];
           }
         }
-        s = team_sum<TEAM>(s, tid);
-        if (lane == 0) featl[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
+        for (int i = 0; i < TEAM; i++) {
+          const int b = c0 + i * TPG + team;
+          if (b >= p.n_bands) break;
+          const int s0 = pick(d_s0, i), s1 = pick(d_s1, i);
+          float s = 0.f;
+          add_bins(s, pick(d_lo, i), pick(d_hi, i));
+          for (int sg = s0 + 1; sg < s1; sg++) add_bins(s, tab[96 + sg], tab[256 + sg]);
+          s = team_sum<TEAM>(s, tid);
+          if (lane == 0) featl[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
+        }
       }
     }
     if constexpr (G::XWAVE) __syncthreads();
@@ -1040,6 +1068,24 @@ CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg, in
   if (left > window) left = window;
   if (left < 0) left = 0;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
+}
+
+// Epoch groups [g0, g0 + n_local) of a streaming workgroup (graded launch: launch_cfg).
+struct StreamSpan {
+  long long g0;
+  int epw, n_local;
+};
+template <int R3>
+CRN_DEV StreamSpan stream_span(const SenseParams &p) {
+  using G = Geo<R3>;
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  const bool big = (long long)blockIdx.x < p.n_big_wgs;
+  StreamSpan s;
+  s.epw = big ? p.groups_per_wg : 1;
+  s.g0 = big ? (long long)blockIdx.x * p.groups_per_wg
+             : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs);
+  s.n_local = (int)((n_groups - s.g0) < s.epw ? (n_groups - s.g0) : s.epw);
+  return s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1106,6 +1152,47 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   cx ua[16], ub[16];
   [[maybe_unused]] cx u0[16];
 
+  if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH && (C::OPT & kMulti) != 0 && G::GROUPS == 1) {
+    if (p.frame_stride * 2 == G::N && p.epoch_stride == (long long)K * (G::N / 2)) {
+      // Welch (hop = N/2) over dense epochs, one epoch per 256 threads: the workgroup's epochs are one
+      // uninterrupted stream of half-frames H(g) = samples [g N/2, (g+1) N/2) — frame g = H(g) | H(g+1),
+      // and the half an epoch ends with is the half the next one starts with.  Three half-frame
+      // register sets: two hold the current frame's raw samples, the third receives H(g+2) while
+      // frame g is computed, so every sample is fetched once per workgroup and the prefetch runs
+      // across epoch boundaries; the close fires after every K-th frame.
+      constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
+      const StreamSpan sp = stream_span<R3>(p);
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, sp.g0, sp.epw);
+      load_frame<R3, NT>(ua, rs, voff, 0u);
+      cx h0[8], h1[8], hn[16];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        h0[r] = ua[r];
+        h1[r] = ua[8 + r];
+      }
+      const int F = sp.n_local * K;
+      int f = 0, j = 0;
+      for (int g = 0; g < F; g++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          ub[r] = h0[r];
+          ub[8 + r] = h1[r];
+        }
+        frame_compute<C, true, true>(ub, c, f, &hn, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          h0[r] = h1[r];
+          h1[r] = hn[r];
+        }
+        if (++f == K) {
+          f = 0;
+          epoch_close<C>(c, p, (sp.g0 + j) * G::GROUPS);
+          j++;
+        }
+      }
+      return;
+    }
+  }
   {
     const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
@@ -1194,12 +1281,9 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       // machine drains in steps of one epoch instead of one 4-epoch workgroup (measured with
       // s_memrealtime stamps: the last 1024 workgroups used to finish spread over 200 us of a
       // 1.4 ms kernel).
-      const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
-      const bool big = (long long)blockIdx.x < p.n_big_wgs;
-      const int epw = big ? p.groups_per_wg : 1;
-      const long long g0 = big ? (long long)blockIdx.x * p.groups_per_wg
-                               : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs);
-      const int n_local = (int)((n_groups - g0) < epw ? (n_groups - g0) : epw);
+      const StreamSpan sp = stream_span<R3>(p);
+      const int epw = sp.epw, n_local = sp.n_local;
+      const long long g0 = sp.g0;
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, g0, epw);
       const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * 8u;
       load_frame<R3, NT>(ua, rs, voff, 0u);
@@ -1256,8 +1340,11 @@ template <class C>
 static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   using G = Geo<C::R3>;
   const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  // Welch (hop = N/2) streams only in the dense one-epoch-per-workgroup-width case (see sense_kernel)
+  const bool welch = C::WIN && p.frame_stride * 2 == G::N;
+  const bool welch_stream = welch && G::GROUPS == 1 && p.epoch_stride == (long long)p.K * (G::N / 2);
   const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
-                     !(C::WIN && p.frame_stride * 2 == G::N);
+                     (!welch || welch_stream);
   SenseParams q = p;
   unsigned grid;
   if (multi) {
@@ -1285,22 +1372,28 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
 
 // Default configuration of every size: all mode / window / short-frame combinations.
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti>
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti,
+          int WHICH = 0 /* 0 all, 1 unwindowed kernels only, 2 windowed only */>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
   const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
 #define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
-  if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
-  if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
-  if (regb) {
-    if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
-    if (full) CRN_GO_R(false, false, true);
-    CRN_GO_R(false, false, false);
+  if constexpr (WHICH != 1) {
+    if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
+    if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
   }
-  if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
-  if (full) CRN_GO(false, false, true);
-  CRN_GO(false, false, false);
+  if constexpr (WHICH != 2) {
+    if (regb) {
+      if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
+      if (full) CRN_GO_R(false, false, true);
+      CRN_GO_R(false, false, false);
+    }
+    if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
+    if (full) CRN_GO(false, false, true);
+    CRN_GO(false, false, false);
+  }
+  return hipErrorInvalidValue;
 #undef CRN_GO
 #undef CRN_GO_R
 }
@@ -1350,8 +1443,12 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
     if constexpr (R3 == 4) return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu>(p, mag, win, stream);
     else return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
   } else {
-    if (variant == kDefaultVariant && (mag || win || p.L != Geo<R3>::N))
-      return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
+    // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
+    // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.
+    if (variant == kDefaultVariant && win)
+      return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
+    if (variant == kDefaultVariant && (mag || p.L != Geo<R3>::N))
+      return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
     switch (variant) {
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
       case 2:

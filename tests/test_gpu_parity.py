@@ -520,3 +520,34 @@ def test_graded_workgroups_cover_every_epoch_once(built, n, n_epochs, epw, tail)
     assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
     assert np.array_equal(got["occupancy"], want["occupancy"])
     assert np.array_equal(got["decision"], want["decision"])
+
+
+@pytest.mark.parametrize("n,K,n_epochs,epw", [(4096, 8, 11, 4), (4096, 3, 13, 3), (4096, 1, 9, 4), (2048, 8, 21, 2)])
+def test_welch_stream_across_epochs(built, n, K, n_epochs, epw):
+    """Welch (Hann, hop N/2) with several epochs per workgroup: at N = 4096 the workgroup's epochs are
+    one uninterrupted stream of half-frames (the half an epoch ends with is the half the next one
+    starts with; the prefetch runs across the epoch close); other sizes keep one epoch per workgroup.
+    Also with an explicit epoch stride (gaps between epochs), which must take the per-epoch path."""
+    cfg = cs.cfg_welch(n, K, 64)
+    for b in range(64):
+        cfg.thresh[b] = 1e-3
+    iq, picks = signals.make_epochs(cfg, n_epochs, seed=n + K)
+    s = cs.Sensor(cfg)
+    s.set_variant(100 + epw)
+    got = s.run_host(iq, n_epochs, want_spectrum=True)
+    want = orc.run(cfg, iq, n_epochs, want_spectrum=True)
+    truth = signals.spectrum_f64(cfg, iq, n_epochs)
+    floor = FLOOR if K >= 4 else 1e-1
+    assert per_bin_err(got["spectrum"], truth, floor) < PER_BIN_TOL
+    assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
+    assert np.array_equal(got["occupancy"], want["occupancy"])
+    # gaps: every epoch starts `stride` samples after the previous one (more than K hops)
+    spe = cs.samples_per_epoch(cfg)
+    stride = spe + n // 2 + 64
+    need = (n_epochs - 1) * stride + cs.samples_needed(cfg, 1)
+    rng = np.random.default_rng(5)
+    big = (rng.standard_normal(need * 2) * 1e-2).astype(np.float32)
+    got2 = s.run_host(big, n_epochs, epoch_stride=stride)
+    want2 = orc.run(cfg, big, n_epochs, epoch_stride=stride)
+    assert np.allclose(got2["features"], want2["features"], rtol=1e-5, atol=0)
+    s.close()
