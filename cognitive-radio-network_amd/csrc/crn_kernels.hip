@@ -946,6 +946,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     if constexpr (G::XWAVE) __syncthreads();
     else wave_sync();
 
+    if constexpr ((C::OPT & kTrace) != 0) tr1 = __builtin_amdgcn_s_memtime();  // LDS form: spectrum image visible
     if (p.spectrum != nullptr && active) {
       float *dst = p.spectrum + epoch * N;
 #pragma unroll
@@ -955,61 +956,57 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       }
     }
 
-    // band sums (reference .cpp:173-191), one team of lanes per band.  This stretch is pure latency
-    // (the wave has no loads in flight beyond its prefetched frame) and an LDS round trip queues behind
-    // the CU's exchange traffic, so the table walk is taken off the per-band path: lane i of a team
-    // fetches the descriptor (segment range, first segment's bins) of the team's i-th band — all
-    // lanes at once, two round trips per TEAM bands instead of two per band — and the band loop picks
-    // them up with v_readlane.  Then four independent bin reads per trip and the DPP/readlane
-    // reduction.  Bands with more than one segment walk the rest of the table as before.
+    // band sums (reference .cpp:173-191).  This stretch is pure latency (the wave has no loads in
+    // flight beyond its prefetched frame), every LDS round trip queues behind the CU's exchange
+    // traffic, and a dependent VALU chain issues one instruction per ~10 cycles — so the work is
+    // spread over lanes instead of bands (one team per band, 16 bands in sequence per wave, cost
+    // the 64-band Welch kernel 11 us per epoch, 40 % of the wave's time):
+    //   every thread sums the 16 consecutive bins of "its" block (thread t: bins 16 t .. 16 t + 15,
+    //   ascending like the reference) -> blk[t]; the 16 lanes of a DPP row add their block totals
+    //   -> rows[t / 16] (256 bins);  then ONE LANE PER BAND walks its segments in steps of 256, 16
+    //   and 1 bins (at most 15 + 15 + 16 + 15 + 15 reads), all bands at once.
+    lds_f32 *blk = featl + 80;  // [T] block totals (behind the CRN_MAX_BANDS features)
+    lds_f32 *rows = blk + T;                 // [R3] row totals
     {
-      const int team = t / TEAM;
-      const int half = TEAM == 32 ? (tid & 32) : 0;
-      auto pick = [&](int v, int i) {  // lane i of this team -> every lane (i uniform)
-        const int a0 = __builtin_amdgcn_readlane(v, i);
-        if constexpr (TEAM == 32) {
-          const int a1 = __builtin_amdgcn_readlane(v, 32 + i);
-          return half ? a1 : a0;
-        }
-        return a0;
-      };
-      auto add_bins = [&](float &s, int lo, int hi) {
-        for (int k0 = lo + lane; k0 < hi; k0 += 4 * TEAM) {
-          float v[4];
+      float bs = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int k = k0 + i * TEAM;
-            const float x = spec[spec_phys(k < hi ? k : lo)];
-            v[i] = k < hi ? x : 0.f;
-          }
-          s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-      };
-      for (int c0 = 0; c0 < p.n_bands; c0 += TEAM * TPG) {  // TEAM bands per team and chunk
-        const int mine = c0 + lane * TPG + team;            // the band whose descriptor this lane fetches
-        int d_s0 = 0, d_s1 = 0, d_lo = 0, d_hi = 0;
-        if (mine < p.n_bands) {
-          d_s0 = tab[mine];
-          d_s1 = tab[mine + 1];
-          if (d_s1 > d_s0) {
-            d_lo = tab[96 + d_s0];
-            d_hi = tab[256 + d_s0];
-          }
-        }
-        for (int i = 0; i < TEAM; i++) {
-          const int b = c0 + i * TPG + team;
-          if (b >= p.n_bands) break;
-          const int s0 = pick(d_s0, i), s1 = pick(d_s1, i);
-          float s = 0.f;
-          add_bins(s, pick(d_lo, i), pick(d_hi, i));
-          for (int sg = s0 + 1; sg < s1; sg++) add_bins(s, tab[96 + sg], tab[256 + sg]);
-          s = team_sum<TEAM>(s, tid);
-          if (lane == 0) featl[b] = MAG ? s * s : __fdiv_rn(s, Kf);  // .cpp:194-197
-        }
-      }
+      for (int j = 0; j < 16; j++) bs += spec[17 * t + j];  // spec_phys(16 t + j)
+      blk[t] = bs;
+      float rs = dpp_add<0xB1>(bs);   // the 16 block totals of a 256-bin row sit in one DPP row
+      rs = dpp_add<0x4E>(rs);
+      rs = dpp_add<0x141>(rs);
+      rs = dpp_add<0x140>(rs);
+      if ((t & 15) == 0) rows[t >> 4] = rs;
     }
     if constexpr (G::XWAVE) __syncthreads();
     else wave_sync();
+    for (int b = t; b < p.n_bands; b += T) {
+      float sum = 0.f;
+      const int s0 = tab[b], s1 = tab[b + 1];
+      for (int sg = s0; sg < s1; sg++) {
+        int k = tab[96 + sg];
+        const int hi = tab[256 + sg];
+        while (k < hi && (k & 15) != 0) sum += spec[spec_phys(k++)];
+        while (k + 16 <= hi && (k & 255) != 0) {
+          sum += blk[k >> 4];
+          k += 16;
+        }
+        while (k + 256 <= hi) {
+          sum += rows[k >> 8];
+          k += 256;
+        }
+        while (k + 16 <= hi) {
+          sum += blk[k >> 4];
+          k += 16;
+        }
+        while (k < hi) sum += spec[spec_phys(k++)];
+      }
+      featl[b] = MAG ? sum * sum : __fdiv_rn(sum, Kf);  // .cpp:194-197
+    }
+    if constexpr ((C::OPT & kTrace) != 0) tr2 = __builtin_amdgcn_s_memtime();  // LDS form: this wave's band sums done
+    if constexpr (G::XWAVE) __syncthreads();
+    else wave_sync();
+    if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();  // LDS form: every feature written
 
     feat = featl;
 
@@ -1433,7 +1430,7 @@ static constexpr int kDefaultVariant = 13;
 // The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
-  if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || win || p.L != Geo<R3>::N)
+  if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || (win && variant != 17) || p.L != Geo<R3>::N)
     variant = kDefaultVariant;
   // Windowed kernels carry 16 more registers (the window): 3 workgroups per CU, all twiddles in
   // registers.  Everything else runs 4 per CU with the compressed pass-1 table and pass 2 from LDS.
@@ -1445,7 +1442,9 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   } else {
     // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
     // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.
-    if (variant == kDefaultVariant && win)
+    if (variant == 17 && win && !mag && p.L == Geo<R3>::N)  // measurement aid: close stamps for the windowed / Welch kernel
+      return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kSpread | kLdsBlk | kPrioValu | kMulti | kTrace>>(p, stream);
+    if (win)
       return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
     if (variant == kDefaultVariant && (mag || p.L != Geo<R3>::N))
       return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
