@@ -928,6 +928,16 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       if (active && in && p.features != nullptr) p.features[epoch * p.n_bands + lane] = f;
     }
   } else {
+    // descriptor of this lane's first band (one lane per band below): fetched now, used after the barriers
+    int pre_s0 = 0, pre_s1 = 0, pre_lo = 0, pre_hi = 0;
+    if (t < p.n_bands) {
+      pre_s0 = tab[t];
+      pre_s1 = tab[t + 1];
+      if (pre_s1 > pre_s0) {
+        pre_lo = tab[96 + pre_s0];
+        pre_hi = tab[256 + pre_s0];
+      }
+    }
     if constexpr (G::XWAVE) __syncthreads();
     else wave_sync();
 #pragma unroll
@@ -980,24 +990,39 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     }
     if constexpr (G::XWAVE) __syncthreads();
     else wave_sync();
+    // four block (or row) totals per LDS round trip, added in ascending order
+    auto add_run = [&](float &sum, const lds_f32 *tot, int i, int n) {  // tot[i .. i + n)
+      for (; n >= 4; n -= 4, i += 4) {
+        const float a0 = tot[i], a1 = tot[i + 1], a2 = tot[i + 2], a3 = tot[i + 3];
+        sum += a0;
+        sum += a1;
+        sum += a2;
+        sum += a3;
+      }
+      for (; n > 0; n--, i++) sum += tot[i];
+    };
     for (int b = t; b < p.n_bands; b += T) {
       float sum = 0.f;
-      const int s0 = tab[b], s1 = tab[b + 1];
+      const bool first = b == t;  // this lane's first band: descriptor fetched before the barriers
+      const int s0 = first ? pre_s0 : tab[b], s1 = first ? pre_s1 : tab[b + 1];
       for (int sg = s0; sg < s1; sg++) {
-        int k = tab[96 + sg];
-        const int hi = tab[256 + sg];
+        int k = (first && sg == s0) ? pre_lo : tab[96 + sg];
+        const int hi = (first && sg == s0) ? pre_hi : tab[256 + sg];
         while (k < hi && (k & 15) != 0) sum += spec[spec_phys(k++)];
-        while (k + 16 <= hi && (k & 255) != 0) {
-          sum += blk[k >> 4];
-          k += 16;
-        }
-        while (k + 256 <= hi) {
-          sum += rows[k >> 8];
-          k += 256;
-        }
-        while (k + 16 <= hi) {
-          sum += blk[k >> 4];
-          k += 16;
+        if (k + 16 <= hi) {
+          // whole blocks up to the next row boundary, whole rows, whole blocks after them
+          int n = ((hi - k) >> 4);                       // whole blocks available
+          const int to_row = ((256 - (k & 255)) & 255) >> 4;  // blocks until k is row-aligned
+          const int head = n < to_row ? n : to_row;
+          add_run(sum, blk, k >> 4, head);
+          k += head * 16;
+          n -= head;
+          const int nrows = n >> 4;
+          add_run(sum, rows, k >> 8, nrows);
+          k += nrows * 256;
+          n -= nrows * 16;
+          add_run(sum, blk, k >> 4, n);
+          k += n * 16;
         }
         while (k < hi) sum += spec[spec_phys(k++)];
       }
