@@ -1457,13 +1457,13 @@ template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || (win && variant != 17) || p.L != Geo<R3>::N)
     variant = kDefaultVariant;
-  // Windowed kernels carry 16 more registers (the window): 3 workgroups per CU, all twiddles in
-  // registers.  Everything else runs 4 per CU with the compressed pass-1 table and pass 2 from LDS.
+  // The plain 4096-point kernel runs 4 workgroups per CU with the compressed pass-1 table and pass 2
+  // from LDS; everything else 3 per CU (windowed kernels carry 16 more registers: the window).
   if constexpr (R3 != 16) {
-    // N = 1024 (one wave per frame) runs one epoch group per workgroup: the streaming loop costs it
-    // registers (spills inside the frame loop) and loses 3 %; the other sizes gain 2.5-3 % from it.
-    if constexpr (R3 == 4) return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu>(p, mag, win, stream);
-    else return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
+    // 3 workgroups per CU, all 30 twiddles in registers (4 per CU with the compressed tables was
+    // measured at these sizes: equal at 1024, -3 % at 512, -7 % at 2048), streaming workgroups
+    // (+2.5-3 % everywhere; N = 1024 used to spill with them until the epoch close was slimmed).
+    return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
   } else {
     // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
     // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.
