@@ -1186,32 +1186,38 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       const StreamSpan sp = stream_span<R3>(p);
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, sp.g0, sp.epw);
       load_frame<R3, NT>(ua, rs, voff, 0u);
-      cx h0[8], h1[8], hn[16];
+      // Three half-frame sets whose roles rotate (current low half, current high half, incoming):
+      // the loop is unrolled by three so the rotation is a renaming, not 16 register moves a frame.
+      cx ha[16], hb[16], hc[16];  // only [0, 8) of each is used (frame_compute's prefetch target is a cx[16])
 #pragma unroll
       for (int r = 0; r < 8; r++) {
-        h0[r] = ua[r];
-        h1[r] = ua[8 + r];
+        ha[r] = ua[r];
+        hb[r] = ua[8 + r];
       }
       const int F = sp.n_local * K;
-      int f = 0, j = 0;
-      for (int g = 0; g < F; g++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          ub[r] = h0[r];
-          ub[8 + r] = h1[r];
-        }
-        frame_compute<C, true, true>(ub, c, f, &hn, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          h0[r] = h1[r];
-          h1[r] = hn[r];
-        }
-        if (++f == K) {
-          f = 0;
-          epoch_close<C>(c, p, (sp.g0 + j) * G::GROUPS);
-          j++;
-        }
+      int f = 0, j = 0, g = 0;
+#define CRN_WELCH_STEP(LO, HI, IN)                                                                  \
+      {                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 8; r++) {                                             \
+          ub[r] = LO[r];                                                                            \
+          ub[8 + r] = HI[r];                                                                        \
+        }                                                                                           \
+        frame_compute<C, true, true>(ub, c, f, &IN, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere); \
+        if (++f == K) {                                                                             \
+          f = 0;                                                                                    \
+          epoch_close<C>(c, p, (sp.g0 + j) * G::GROUPS);                                            \
+          j++;                                                                                      \
+        }                                                                                           \
+        g++;                                                                                        \
       }
+      while (g < F) {
+        CRN_WELCH_STEP(ha, hb, hc)
+        if (g >= F) break;
+        CRN_WELCH_STEP(hb, hc, ha)
+        if (g >= F) break;
+        CRN_WELCH_STEP(hc, ha, hb)
+      }
+#undef CRN_WELCH_STEP
       return;
     }
   }
