@@ -10,6 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense.so")  # env override: A/B builds
+LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
 CRN_ABI_VERSION = 1
 CRN_MAX_BANDS = 80
@@ -23,7 +24,8 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
-    "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
+    "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy",
     "crn_last_error", "crn_abi_version",
@@ -106,6 +108,8 @@ def lib():
                                                C.c_void_p, C.c_void_p]
         L.crn_ann_train_device.argtypes = [C.c_void_p, C.POINTER(TrainCfg), C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        L.crn_fft_forward_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
+                                             C.c_void_p]
         L.crn_sense_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
@@ -221,6 +225,11 @@ class Sensor:
         check(lib().crn_synth_fill_device_ex(self._h, C.byref(sc), iq_ptr, n_epochs, spe,
                                              C.c_void_p(truth_ptr or None), C.c_void_p(stream or None)),
               "crn_synth_fill_device_ex")
+
+    def fft_forward_device(self, in_ptr, n_frames, L, out_ptr, frame_stride=0, stream=0):
+        """Unnormalised forward DFT of n_frames frames (device pointers)."""
+        check(lib().crn_fft_forward_device(self._h, in_ptr, n_frames, L, frame_stride, out_ptr,
+                                           C.c_void_p(stream or None)), "crn_fft_forward_device")
 
     def ann_train_device(self, tc, feat_ptr, label_ptr, n, stream=0):
         """Fit the 4-5-3 network to device-resident features/labels; returns (w_ih, w_ho, loss)."""

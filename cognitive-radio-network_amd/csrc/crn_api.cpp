@@ -427,6 +427,26 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   return CRN_OK;
 }
 
+int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, int32_t samples_per_frame,
+                           int64_t frame_stride, float *d_out, void *stream) {
+  if (!h || !d_in || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
+  if (n_frames < 0) return crn::fail(CRN_ERR_ARG, "negative frame count");
+  if (samples_per_frame < 1 || samples_per_frame > h->cfg.fft_len)
+    return crn::fail(CRN_ERR_ARG, "samples_per_frame must be in 1..fft_len");
+  if (frame_stride <= 0) frame_stride = samples_per_frame;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  crn::FftParams p{};
+  p.in = reinterpret_cast<const float2 *>(d_in);
+  p.out = reinterpret_cast<float2 *>(d_out);
+  p.n_frames = n_frames;
+  p.frame_stride = frame_stride;
+  p.L = samples_per_frame;
+  p.tw1 = h->d_tw1;
+  p.tw2 = h->d_tw2;
+  HIP_TRY(crn::launch_fft(p, h->cfg.fft_len, static_cast<hipStream_t>(stream)));
+  return CRN_OK;
+}
+
 int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs, int64_t samples_per_epoch,
                           uint64_t seed, float noise_power, float signal_rms, int32_t tones_per_band,
                           int32_t *d_truth, void *stream) {

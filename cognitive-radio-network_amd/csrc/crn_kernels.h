@@ -77,6 +77,16 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 int sense_num_variants();
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
+struct FftParams {
+  const float2 *in;        // [n_frames] frames of L samples, frame_stride samples apart
+  float2 *out;             // [n_frames][N]
+  long long n_frames;
+  long long frame_stride;
+  int L;                   // samples taken per frame (zero-padded to N)
+  const float2 *tw1;       // [17][T]
+  const float2 *tw2;       // [16][R3]
+};
+hipError_t launch_fft(const FftParams &p, int fft_len, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 

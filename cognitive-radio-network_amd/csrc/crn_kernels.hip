@@ -485,10 +485,9 @@ CRN_DEV void ph_x2_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
 // pass 3: DFT_R3 over m_lo -> d; bin k = a + 16 (g J + j) + 256 d; then the per-bin accumulate
 // over the epoch (reference: fft_avg[i] += cabsf(X[i]) / K, CE_Predictive_Node.cpp:152-154)
 template <class C>
-CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+CRN_DEV void ph_pass3(cx (&u)[16], cx (&v)[16]) {
   constexpr int R3 = C::R3, J = Geo<R3>::J;
   using m = M<C::PK>;
-  cx v[16];
   if constexpr (R3 == 16) {
     dft16<C::PK>(u, v);
   } else if constexpr (R3 == 8) {
@@ -515,6 +514,13 @@ CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
       v[j * 2 + 1] = m::sub(u[j * 2], u[j * 2 + 1]);
     }
   }
+}
+
+// pass 3 + per-bin accumulate: v[j * R3 + d] is bin a + 16 (m_lo J + j) + 256 d
+template <class C>
+CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+  cx v[16];
+  ph_pass3<C>(u, v);
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     if constexpr (C::MAG) {
@@ -1551,6 +1557,86 @@ void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int 
   *epochs_per_block = groups;
   (void)tl;
   *lds_bytes = (groups * nbuf * 16 * (t + r3) + 16 * r3) * 8 + kCloseLdsBytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain batched forward FFT (complex in, complex out): the transform of sense_kernel on its own, for
+// callers that bind the liquid-dsp entry points the reference calls (include/crn_liquid_fft.h;
+// CE_Predictive_Node.cpp:42-45,150).  One frame per T = N/16 threads, the same three passes and two
+// exchanges; the spectrum goes back through the exchange buffer in natural order so the global
+// stores are coalesced.  Not the hot path: no prefetch, no streaming.
+// ---------------------------------------------------------------------------------------------
+template <int R3>
+__global__ __launch_bounds__(256, 2) void fft_kernel(const FftParams p) {
+  using C = Cfg<R3, 1, false, false, false, false, false, 2, 0, false, true, kLdsBlk>;
+  using G = Geo<R3>;
+  constexpr int T = G::T, N = G::N, J = G::J;
+  extern __shared__ __attribute__((aligned(16))) cx lds[];
+  const int tid = threadIdx.x;
+  const int grp = tid / T, t = tid % T;
+  FrameCtx<C> c;
+  c.t = t;
+  c.a = t / R3;
+  c.m_lo = t % R3;
+  c.L = p.L;
+  c.gbuf = lds + grp * G::GROUP_CPLX;
+  c.tw2_lds = nullptr;
+#pragma unroll
+  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+#pragma unroll
+  for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + c.m_lo];
+  const long long fr = (long long)blockIdx.x * G::GROUPS + grp;
+  const bool live = fr < p.n_frames;
+  cx u[16], v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int n = t + T * r;
+    u[r] = (live && n < p.L) ? reinterpret_cast<const cx *>(p.in)[fr * p.frame_stride + n] : cx{0.f, 0.f};
+  }
+  ph_pass1<C>(u, v, c);
+  ph_x1_write<C>(v, c.gbuf, c);
+  group_sync<C>();
+  ph_x1_read<C>(u, c.gbuf, c);
+  ph_pass2<C>(u, v, c);
+  wave_sync();
+  ph_x2_write<C>(v, c.gbuf, c);
+  wave_sync();
+  ph_x2_read<C>(u, c.gbuf, c);
+  ph_pass3<C>(u, v);
+  group_sync<C>();  // every wave of the group is done with the exchange buffer
+#pragma unroll
+  for (int j = 0; j < J; j++)
+#pragma unroll
+    for (int d = 0; d < R3; d++) {
+      const int k = c.a + 16 * (c.m_lo * J + j) + 256 * d;
+      c.gbuf[spec_phys(k)] = v[j * R3 + d];
+    }
+  group_sync<C>();
+  if (live) {
+    cx *dst = reinterpret_cast<cx *>(p.out) + fr * N;
+#pragma unroll
+    for (int r = 0; r < 16; r++) dst[t + T * r] = c.gbuf[spec_phys(t + T * r)];
+  }
+}
+
+template <int R3>
+static hipError_t launch_fft_r(const FftParams &p, hipStream_t stream) {
+  using G = Geo<R3>;
+  const long long grid = (p.n_frames + G::GROUPS - 1) / G::GROUPS;
+  if (grid <= 0) return hipSuccess;
+  const size_t lds = (size_t)G::GROUPS * G::GROUP_CPLX * sizeof(cx);
+  hipLaunchKernelGGL(fft_kernel<R3>, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fft(const FftParams &p, int fft_len, hipStream_t stream) {
+  switch (fft_len) {
+    case 512: return launch_fft_r<2>(p, stream);
+    case 1024: return launch_fft_r<4>(p, stream);
+    case 2048: return launch_fft_r<8>(p, stream);
+    case 4096: return launch_fft_r<16>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

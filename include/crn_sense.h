@@ -219,6 +219,16 @@ CRN_API int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_re
 CRN_API int crn_ingest_drain(crn_ingest *g);
 CRN_API int crn_ingest_destroy(crn_ingest *g);
 
+/* -- the transform on its own ------------------------------------------------------------------
+ * Unnormalised forward DFT X[k] = sum_n x[n] exp(-j 2 pi k n / N) (the contract of liquid-dsp's
+ * fft_execute with LIQUID_FFT_FORWARD, CE_Predictive_Node.cpp:42-45,150) of n_frames frames:
+ * frame i takes samples_per_frame (<= fft_len, zero-padded) interleaved complex fp32 samples starting
+ * frame_stride samples (0 = samples_per_frame) after frame i-1, and yields fft_len complex bins at
+ * d_out + 2 * fft_len * i.  Same passes as the sensing kernel, complex output instead of the fused
+ * accumulate.  include/crn_liquid_fft.h puts liquid's three entry points on top of this. */
+CRN_API int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, int32_t samples_per_frame,
+                                   int64_t frame_stride, float *d_out, void *stream);
+
 /* -- training -------------------------------------------------------------
  * The reference ships weights for one FFT size and one receiver gain (CE_Predictive_Node.cpp:78-120)
  * and no way to make others.  crn_ann_train_device fits the same 4-5-3 sigmoid network
