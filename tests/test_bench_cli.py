@@ -1,0 +1,42 @@
+"""bench.py's contract (one JSON line on stdout with roofline and cpu_baseline), and the N > 1 code path
+dry-run on one GPU: RCCL group of one rank, occupancy all-gather overlapped with the next launch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
+                          "--epochs", "512", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout            # exactly one line, whatever the libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
+    d = _run("--cpu-epochs", "64")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "epochs" in c["sample"]
+    assert d["config"]["workload"].startswith("4096-pt")
+
+
+@pytest.mark.parametrize("mode", [[], ["--mode", "ref"], ["--mode", "welch"]])
+def test_bench_collective_path_on_one_gpu(built, mode):
+    d = _run("--cpu-epochs", "0", "--force-collective", *mode)
+    assert "RCCL all-gather of occupancy" in d["config"]["parallelism"]
+    assert d["value"] > 0 and d["cpu_baseline"] is None
