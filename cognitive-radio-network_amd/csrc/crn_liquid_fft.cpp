@@ -15,6 +15,7 @@ struct fftplan_s {
   crn_handle *h;
   float *d_in, *d_out;
   hipStream_t stream;
+  bool pinned_x, pinned_y;  // the caller's arrays page-locked for the copies (best effort)
 };
 
 namespace {
@@ -41,6 +42,10 @@ extern "C" fftplan fft_create_plan(unsigned int n, liquid_float_complex *x, liqu
   if (hipSetDevice(cfg.device) != hipSuccess || hipMalloc(&p->d_in, sizeof(float) * 2 * n) != hipSuccess ||
       hipMalloc(&p->d_out, sizeof(float) * 2 * n) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess)
     die("device buffers", hipGetErrorString(hipGetLastError()));
+  // page-lock the bound arrays: the two copies of every fft_execute then go straight over DMA
+  p->pinned_x = hipHostRegister(x, sizeof(float) * 2 * n, hipHostRegisterDefault) == hipSuccess;
+  p->pinned_y = hipHostRegister(y, sizeof(float) * 2 * n, hipHostRegisterDefault) == hipSuccess;
+  (void)hipGetLastError();
   return p;
 }
 
@@ -57,6 +62,8 @@ extern "C" void fft_execute(fftplan p) {
 
 extern "C" void fft_destroy_plan(fftplan p) {
   if (!p) return;
+  if (p->pinned_x) (void)hipHostUnregister(p->x);
+  if (p->pinned_y) (void)hipHostUnregister(p->y);
   (void)hipStreamDestroy(p->stream);
   (void)hipFree(p->d_in);
   (void)hipFree(p->d_out);
