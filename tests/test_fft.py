@@ -143,3 +143,28 @@ def test_reference_epoch_loop_over_the_liquid_entry_points(built):
         assert np.abs(out3 - ref["ann_out"]).max() < 1e-6
     lib.fft_destroy_plan(plan)
     print(f"fft_execute over the shim: median {np.median(t_exec) * 1e6:.0f} us per 512-point call")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_forward_fft_against_rocfft(built, n):
+    """Third, independent cross-check (test side only; the product never links rocFFT): torch.fft.fft on
+    the same device buffer, complex64, which is rocFFT's plan for that size."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n)
+    frames = 64
+    x = torch.randn(frames, n, 2, generator=g, device=dev, dtype=torch.float32)
+    out = torch.zeros(frames, n, 2, device=dev, dtype=torch.float32)
+    s = cs.Sensor(cs.cfg_energy_scaled(n, 4.0))
+    s.fft_forward_device(x.data_ptr(), frames, n, out.data_ptr())
+    torch.cuda.synchronize()
+    s.close()
+    ref = torch.fft.fft(torch.view_as_complex(x), dim=1)
+    got = torch.view_as_complex(out)
+    rms = ref.abs().pow(2).mean().sqrt()
+    assert ((got - ref).abs().max() / rms).item() < 1e-5
+    ref64 = torch.fft.fft(torch.view_as_complex(x.double()), dim=1)
+    ours = ((got.to(torch.complex128) - ref64).abs().max() / rms).item()
+    theirs = ((ref.to(torch.complex128) - ref64).abs().max() / rms).item()
+    assert ours < 2.0 * theirs + 1e-6, (ours, theirs)   # as close to float64 as the vendor library
