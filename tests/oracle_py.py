@@ -12,7 +12,7 @@ import crnsense as cs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libcrn_oracle.so")
+ORACLE_LIB = os.environ.get("CRN_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libcrn_oracle.so")  # env: sanitizer build
 
 _lib = None
 
