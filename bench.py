@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--fft", type=int, default=4096, help="FFT length N (headline: 4096)")
     ap.add_argument("--epochs", type=int, default=0, help="decision epochs per GPU per step (0 = 8.75 GiB of IQ)")
-    ap.add_argument("--mode", choices=["energy", "ref", "welch"], default="energy")
+    ap.add_argument("--mode", choices=["energy", "ref", "welch", "scan"], default="energy",
+                    help="scan = cfg4's wideband scan: the welch kernel, streams of 64 channels sharded over the ranks")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--frames", type=int, default=0, help="frames per epoch K (0 = the configuration's own, 10)")
     ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip)")
@@ -87,11 +88,16 @@ def main():
     if args.mode == "ref":
         cfg = cs.cfg_reference()
         workload = "cfg3: 512-pt |X| mean x10 + 4-5-3 ANN cascade (reference-exact)"
-    elif args.mode == "welch":
+    elif args.mode in ("welch", "scan"):
         cfg = cs.cfg_welch(args.fft, 8, 64)
         for b in range(64):
             cfg.thresh[b] = 1e-2
         workload = f"cfg2: {args.fft}-pt Welch PSD (Hann, 50% overlap) x 64 bands + threshold"
+        if args.mode == "scan":
+            # BASELINE.json configs[4]: 256 channels = 4 streams x 64 bands is the shard unit; a rank's batch
+            # is thousands of such units (one epoch of one stream each), the occupancy gather is [epochs, 64]
+            workload = (f"cfg4: wideband scan, {args.fft}-pt Welch x 64 channels per stream (256 channels = 4 streams), "
+                        "streams sharded over the ranks, occupancy all-gather")
     else:
         cfg = cs.cfg_energy_scaled(args.fft, 4.0)
         workload = f"{args.fft}-pt FFT + energy detect x 3ch (+noise-floor band), K=10, threshold"
@@ -209,7 +215,7 @@ def main():
     if os.path.exists(args.traffic_json):
         try:
             tj = json.load(open(args.traffic_json))
-            key = f"{args.mode}{N}"
+            key = f"{'welch' if args.mode == 'scan' else args.mode}{N}"
             if key in tj:  # measured once per kernel; scales linearly with the batch
                 traffic = int(tj[key]["hbm_bytes_per_launch"] * (E / tj[key]["epochs"]))
         except Exception:

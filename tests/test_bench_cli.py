@@ -35,7 +35,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
     assert d["config"]["workload"].startswith("4096-pt")
 
 
-@pytest.mark.parametrize("mode", [[], ["--mode", "ref"], ["--mode", "welch"]])
+@pytest.mark.parametrize("mode", [[], ["--mode", "ref"], ["--mode", "welch"], ["--mode", "scan"]])
 def test_bench_collective_path_on_one_gpu(built, mode):
     d = _run("--cpu-epochs", "0", "--force-collective", *mode)
     assert "RCCL all-gather of occupancy" in d["config"]["parallelism"]
