@@ -336,6 +336,7 @@ struct FrameCtx {
   float acc[16];
   const cx *tw2_lds;
   int wave;           // wave index in the workgroup (SGPR)
+  int grp_epoch_stride;  // epoch of lane group g = epoch_base + g * this (1; the Welch stream deals epochs in runs)
   unsigned lds_base;  // LDS byte offset of the dynamic segment (SGPR); the band table copy sits behind tw2
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
@@ -803,7 +804,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   if constexpr ((C::OPT & kPrioValu) != 0 && G::XWAVE) __builtin_amdgcn_s_setprio(3);
   const int tid = c.wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int t = tid % T, grp = tid / T;
-  const long long epoch = epoch_base + grp;
+  const long long epoch = epoch_base + (long long)grp * c.grp_epoch_stride;
   const bool active = epoch < p.n_epochs;
   const int a = t / R3, m_lo = t % R3;
   [[maybe_unused]] unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.L = p.L;
   c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.grp_epoch_stride = 1;
   c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
   c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
   const int K = p.K;
@@ -1180,17 +1182,22 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   cx ua[16], ub[16];
   [[maybe_unused]] cx u0[16];
 
-  if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH && (C::OPT & kMulti) != 0 && G::GROUPS == 1) {
+  if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH && (C::OPT & kMulti) != 0) {
     if (p.frame_stride * 2 == G::N && p.epoch_stride == (long long)K * (G::N / 2)) {
-      // Welch (hop = N/2) over dense epochs, one epoch per 256 threads: the workgroup's epochs are one
-      // uninterrupted stream of half-frames H(g) = samples [g N/2, (g+1) N/2) — frame g = H(g) | H(g+1),
-      // and the half an epoch ends with is the half the next one starts with.  Three half-frame
-      // register sets: two hold the current frame's raw samples, the third receives H(g+2) while
-      // frame g is computed, so every sample is fetched once per workgroup and the prefetch runs
-      // across epoch boundaries; the close fires after every K-th frame.
+      // Welch (hop = N/2) over dense epochs: a lane group's epochs are one uninterrupted stream of
+      // half-frames H(g) = samples [g N/2, (g+1) N/2) — frame g = H(g) | H(g+1), and the half an epoch
+      // ends with is the half the next one starts with.  Three half-frame register sets: two hold the
+      // current frame's raw samples, the third receives H(g+2) while frame g is computed, so every
+      // sample is fetched once per lane group and the prefetch runs across epoch boundaries; the
+      // close fires after every K-th frame.  The workgroup's GROUPS x epw epochs are dealt to its
+      // lane groups in runs of epw (group g: epochs E0 + g epw ...), so that each group's stream is
+      // contiguous; every group runs epw x K frames (the ragged end closes inactive epochs: uniform
+      // barriers, loads past the batch return zero).
       constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
       const StreamSpan sp = stream_span<R3>(p);
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, sp.g0, sp.epw);
+      const unsigned voff = (unsigned)(grp * sp.epw * (unsigned)p.epoch_stride + t) * 8u;  // shadows the per-epoch one
+      c.grp_epoch_stride = sp.epw;
       load_frame<R3, NT>(ua, rs, voff, 0u);
       // Three half-frame sets whose roles rotate (current low half, current high half, incoming):
       // the loop is unrolled by three so the rotation is a renaming, not 16 register moves a frame.
@@ -1200,7 +1207,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         ha[r] = ua[r];
         hb[r] = ua[8 + r];
       }
-      const int F = sp.n_local * K;
+      const int F = (G::GROUPS == 1 ? sp.n_local : sp.epw) * K;
       int f = 0, j = 0, g = 0;
 #define CRN_WELCH_STEP(LO, HI, IN)                                                                  \
       {                                                                                             \
@@ -1211,7 +1218,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         frame_compute<C, true, true>(ub, c, f, &IN, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere); \
         if (++f == K) {                                                                             \
           f = 0;                                                                                    \
-          epoch_close<C>(c, p, (sp.g0 + j) * G::GROUPS);                                            \
+          epoch_close<C>(c, p, sp.g0 * G::GROUPS + j);                                              \
           j++;                                                                                      \
         }                                                                                           \
         g++;                                                                                        \
@@ -1374,9 +1381,9 @@ template <class C>
 static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   using G = Geo<C::R3>;
   const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
-  // Welch (hop = N/2) streams only in the dense one-epoch-per-workgroup-width case (see sense_kernel)
+  // Welch (hop = N/2) streams when the epochs are dense (see sense_kernel)
   const bool welch = C::WIN && p.frame_stride * 2 == G::N;
-  const bool welch_stream = welch && G::GROUPS == 1 && p.epoch_stride == (long long)p.K * (G::N / 2);
+  const bool welch_stream = welch && p.epoch_stride == (long long)p.K * (G::N / 2);
   const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
                      (!welch || welch_stream);
   SenseParams q = p;
@@ -1475,7 +1482,10 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
     // 3 workgroups per CU, all 30 twiddles in registers (4 per CU with the compressed tables was
     // measured at these sizes: equal at 1024, -3 % at 512, -7 % at 2048), streaming workgroups
     // (+2.5-3 % everywhere; N = 1024 used to spill with them until the epoch close was slimmed).
-    return launch_default<R3, 1, true, true, false, 3, true>(p, mag, win, stream);
+    // windowed kernels (16 window registers, and for Welch three half-frame sets) read the pass-2
+    // twiddles from LDS, like the 4096-point ones: in registers they spill inside the frame loop
+    if (win) return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
+    return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
   } else {
     // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
     // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.

@@ -522,12 +522,14 @@ def test_graded_workgroups_cover_every_epoch_once(built, n, n_epochs, epw, tail)
     assert np.array_equal(got["decision"], want["decision"])
 
 
-@pytest.mark.parametrize("n,K,n_epochs,epw", [(4096, 8, 11, 4), (4096, 3, 13, 3), (4096, 1, 9, 4), (2048, 8, 21, 2)])
+@pytest.mark.parametrize("n,K,n_epochs,epw", [(4096, 8, 11, 4), (4096, 3, 13, 3), (4096, 1, 9, 4), (2048, 8, 21, 2),
+                                              (1024, 5, 37, 3), (512, 8, 100, 4), (512, 2, 7, 1)])
 def test_welch_stream_across_epochs(built, n, K, n_epochs, epw):
-    """Welch (Hann, hop N/2) with several epochs per workgroup: at N = 4096 the workgroup's epochs are
-    one uninterrupted stream of half-frames (the half an epoch ends with is the half the next one
-    starts with; the prefetch runs across the epoch close); other sizes keep one epoch per workgroup.
-    Also with an explicit epoch stride (gaps between epochs), which must take the per-epoch path."""
+    """Welch (Hann, hop N/2) with several epochs per workgroup: a lane group's epochs are one
+    uninterrupted stream of half-frames (the half an epoch ends with is the half the next one starts
+    with; the prefetch runs across the epoch close; at N < 4096 the workgroup's epochs are dealt to
+    its lane groups in runs).  Also with an explicit epoch stride (gaps between epochs), which must
+    take the per-epoch path."""
     cfg = cs.cfg_welch(n, K, 64)
     for b in range(64):
         cfg.thresh[b] = 1e-3
