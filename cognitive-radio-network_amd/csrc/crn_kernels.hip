@@ -256,11 +256,15 @@ CRN_DEV cx ld_iq(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
 // u[r] = x[t + T r] of the frame that starts `frame_soff` bytes into the workgroup's window.
 // Branch-free on purpose: a branch between issue and use makes the compiler drain vmcnt at the
 // join, which serialises the prefetch with the compute it is meant to hide.
+constexpr unsigned kOffNowhere = 0x80000000u;  // scalar offset past every window: the buffer range check drops the load
+
+// Rows that lie wholly beyond the L samples a frame brings (short packets: the reference's 364 of
+// 512, CE_Predictive_Node.cpp:149) are not fetched at all: they would be the next frame's samples.
 template <int R3, bool NT>
-CRN_DEV void load_frame(cx (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned frame_soff) {
+CRN_DEV void load_frame(cx (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned frame_soff, int L = Geo<R3>::N) {
   constexpr int T = Geo<R3>::T;
 #pragma unroll
-  for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, frame_soff + (unsigned)(T * r * 8));
+  for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, T * r < L ? frame_soff + (unsigned)(T * r * 8) : kOffNowhere);
 }
 
 // Half a frame: h[r] = x[t + T r], r = 0..7, of the N/2 samples starting `half_soff` bytes into the
@@ -353,11 +357,12 @@ struct SpreadLoads {
   unsigned voff, soff;
   int pass;   // 0 or 1: which of the frame's first two DFT16s this hook sits in
   bool half;  // Welch: only 8 loads (one half-frame), all in pass 1
+  int L;      // samples a frame brings: rows wholly beyond it are not fetched
   __device__ __forceinline__ void operator()(int k) const {
     if (pass > 1 || (half && pass != 0)) return;
     const int idx = pass * 8 + k;
     __builtin_amdgcn_sched_barrier(0);
-    nx[idx] = ld_iq<NT>(rsrc, voff, soff + (unsigned)(Geo<R3>::T * idx * 8));
+    nx[idx] = ld_iq<NT>(rsrc, voff, Geo<R3>::T * idx < L ? soff + (unsigned)(Geo<R3>::T * idx * 8) : kOffNowhere);
     __builtin_amdgcn_sched_barrier(0);
   }
 };
@@ -553,7 +558,8 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
   cx v[16];
   if constexpr (SPREAD) {
     static_assert(C::ABL == 0, "ablations use the plain path");
-    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, HALF}, h2{*nx, rsrc, voff, soff_next, 1, HALF};
+    const int Lrows = C::FULL ? G::N : c.L;
+    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, HALF, Lrows}, h2{*nx, rsrc, voff, soff_next, 1, HALF, Lrows};
     // Waves in passes 1 and 2 (which also issue the next frame's loads) win VALU arbitration
     // against waves in pass 3 / epoch close: measured +1.4 % (76.9 vs 75.8 %); raising pass 1 alone,
     // pass 3 alone or the LDS phases gains nothing.
@@ -1237,7 +1243,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   {
     const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
-    load_frame<R3, NT>(ua, rsrc, voff, 0u);
+    load_frame<R3, NT>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
     if constexpr (C::ABL >= 2) {
 #pragma unroll
       for (int r = 0; r < 16; r++) u0[r] = ua[r];
@@ -1327,7 +1333,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       const long long g0 = sp.g0;
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, g0, epw);
       const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * 8u;
-      load_frame<R3, NT>(ua, rs, voff, 0u);
+      load_frame<R3, NT>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
       int j = 0, f = 0;
 #define CRN_STREAM_STEP(CUR, NXT)                                                                   \
       {                                                                                             \
