@@ -553,3 +553,41 @@ def test_welch_stream_across_epochs(built, n, K, n_epochs, epw):
     want2 = orc.run(cfg, big, n_epochs, epoch_stride=stride)
     assert np.allclose(got2["features"], want2["features"], rtol=1e-5, atol=0)
     s.close()
+
+
+def test_two_handles_on_two_threads(built):
+    """The library is thread-compatible: one handle per thread, no shared mutable state (the reference
+    runs one CE thread per radio, src/extensible_cognitive_radio.cpp:1761-1808; a node process hosts
+    one engine, a test bench may host many).  Two threads, different configurations, concurrent
+    launches: each gets its own results and its own crn_last_error."""
+    import threading
+    jobs = [(cs.cfg_reference(), 41, 364, 11), (cs.cfg_energy_scaled(2048, 4.0), 23, 2048, 12),
+            (cs.cfg_welch(4096, 4, 64), 7, 4096, 13), (cs.cfg_energy_scaled(1024, 4.0), 50, 1024, 14)]
+    results, errors = {}, []
+
+    def work(i, cfg, n_epochs, L, seed):
+        try:
+            if cfg.n_bands == 64:
+                for b in range(64):
+                    cfg.thresh[b] = 1e-3
+            iq, _ = signals.make_epochs(cfg, n_epochs, seed=seed, L=L)
+            s = cs.Sensor(cfg)
+            for _ in range(5):
+                got = s.run_host(iq, n_epochs, L=L)
+            s.close()
+            results[i] = (cfg, iq, n_epochs, L, got)
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i, *j)) for i, j in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert len(results) == len(jobs)
+    for i, (cfg, iq, n_epochs, L, got) in results.items():
+        want = orc.run(cfg, iq, n_epochs, L=L)
+        assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0), i
+        assert np.array_equal(got["decision"], want["decision"]), i
+        assert np.array_equal(got["occupancy"], want["occupancy"]), i
