@@ -140,3 +140,27 @@ def test_oracle_rejects_bad_arguments(built):
     iq = np.zeros(16, np.float32)
     assert orc.lib().crn_oracle_run(C.byref(cfg), iq.ctypes.data, 1, 513, 0, C.byref(o), 1) == -1
     assert orc.lib().crn_oracle_run(C.byref(cfg), iq.ctypes.data, 1, 0, 0, C.byref(o), 1) == -1
+
+
+@pytest.mark.parametrize("n", [1024, 512])
+def test_cfg0_thousand_epochs_cpu_plumbing(built, n):
+    """BASELINE.json configs[0] / SURVEY.md §8d cfg0: 3 channels + noise floor, K = 10, one stream, 1000
+    epochs, CPU restatement only: every decision follows the driven occupancy, with the generated
+    traffic of the generator twin (uniform model) as input.  N = 1024 decides by threshold against the
+    noise-floor band, N = 512 is the reference configuration with its network."""
+    import oracle_py as orc
+    cfg = cs.cfg_energy_scaled(1024, 4.0) if n == 1024 else cs.cfg_reference()
+    sc = cs.SynthCfg()
+    sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 0xC0FFEE, 1e-6, 0.02, 8
+    sc.pu_model, sc.signal_kind, sc.n_streams = cs.PU_UNIFORM, cs.SIG_TONES, 1
+    n_epochs = 1000
+    iq, truth = orc.synth(cfg, sc, n_epochs, cs.samples_per_epoch(cfg))
+    got = orc.run(cfg, iq, n_epochs, n_threads=4)
+    if n == 512:
+        assert np.array_equal(got["decision"], truth)
+    else:
+        want = np.zeros((n_epochs, 4), np.uint8)
+        idx = np.nonzero(truth > 0)[0]
+        want[idx, truth[idx]] = 1
+        assert np.array_equal(got["occupancy"], want)
+    assert set(truth.tolist()) == {0, 1, 2, 3}
