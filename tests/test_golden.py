@@ -1,5 +1,17 @@
-"""Committed fixtures (tests/golden/, generated by make_golden.py): the oracle must keep
-reproducing them (CPU), and the HIP path must match them (GPU)."""
+"""Committed fixtures (tests/golden/, written by make_golden.py from tests/ref_f64.py — the independent
+float64 restatement of SURVEY.md Appendix A, which shares no code with oracle/ or the product).
+
+CPU: the fixtures are re-derived by ref_f64 (the generator must stay reproducible), the C oracle
+must agree with them, SURVEY.md Appendix C's probe values must come out of both, and the product's
+configuration helpers must describe the same band plans.  GPU: the HIP path must agree with the same
+numbers.
+
+Tolerances (fp32 implementations against float64 truth):
+  per-bin K-frame average   |E - E64| <= 1e-5 * max(E64, floor * mean_k E64)   floor: FLOOR_ORACLE / FLOOR_GPU
+  band features             relative 1e-5
+  ANN outputs               absolute 1e-6
+  decisions / occupancy     exact (every fixture epoch is asserted to sit outside the margin band)
+"""
 import json
 import os
 
@@ -8,67 +20,187 @@ import pytest
 
 import crnsense as cs
 import oracle_py as orc
+import ref_f64
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = [("ref512_L364.npz", lambda: cs.cfg_reference()),
-         ("energy1024.npz", lambda: cs.cfg_energy_scaled(1024, 4.0)),
-         ("energy4096.npz", lambda: cs.cfg_energy_scaled(4096, 4.0))]
+
+# The radix-2 fp32 restatement (12 passes at N = 4096) misses 1e-5 at the stated floor of
+# 1e-3 * mean (measured 1.0e-5 / 1.2e-5 / 1.8e-5 / 3.6e-5 at N = 512 .. 4096), so it is held to 1e-2 * mean.
+# The HIP path (3 radix-16 passes) meets 1e-5 at the stated floor for N <= 1024 and is held to it there;
+# at N = 4096 it measures 2.1e-5 at 1e-3 * mean and 5.0e-6 at 1e-2 * mean (tests/test_gpu_parity.py,
+# test_per_bin_error_at_the_stated_floor).
+FLOOR_ORACLE = 1e-2
 
 
-def per_bin_err(spec, truth):
-    floor = 1e-2 * truth.mean(axis=1, keepdims=True)
-    return (np.abs(spec - truth) / np.maximum(truth, floor)).max()
+def floor_gpu(cfg):
+    return 1e-3 if cfg.fft_len <= 1024 else 1e-2
+
+
+def _welch1024():
+    g = np.load(os.path.join(GOLD, "welch1024.npz"))
+    cfg = cs.cfg_welch(1024, 8, 64)
+    for b in range(64):
+        cfg.thresh[b] = float(g["thresh"][b])
+    return cfg, ref_f64.plan_welch(1024, 8, 64, g["thresh"])
+
+
+CASES = [("ref512_L364.npz", lambda: (cs.cfg_reference(), ref_f64.plan_reference())),
+         ("ref512_L512.npz", lambda: (cs.cfg_reference(), ref_f64.plan_reference())),
+         ("energy1024.npz", lambda: (cs.cfg_energy_scaled(1024, 4.0), ref_f64.plan_energy_scaled(1024, 4.0))),
+         ("energy4096.npz", lambda: (cs.cfg_energy_scaled(4096, 4.0), ref_f64.plan_energy_scaled(4096, 4.0))),
+         ("welch1024.npz", _welch1024)]
+
+
+def per_bin_err(spec, truth, floor):
+    lim = np.maximum(truth, floor * truth.mean(axis=1, keepdims=True))
+    return (np.abs(spec - truth) / lim).max()
+
+
+def check_against_golden(got, g, cfg, floor):
+    assert per_bin_err(got["spectrum"], g["spectrum_f64"], floor) < 1e-5
+    rel = np.abs(got["features"] - g["features_f64"]) / np.maximum(np.abs(g["features_f64"]), 1e-300)
+    assert rel.max() < 1e-5, rel.max()
+    assert np.array_equal(got["decision"], g["decision"])
+    assert np.array_equal(got["occupancy"], g["occupancy"])
+    if cfg.decide == cs.DECIDE_ANN:
+        assert np.abs(got["ann_out"] - g["ann_out_f64"]).max() < 1e-6
 
 
 @pytest.mark.parametrize("name,mk", CASES)
-def test_oracle_reproduces_golden(built, name, mk):
+def test_fixture_is_what_the_independent_reference_computes(built, name, mk):
+    """make_golden.py is reproducible, and no fixture epoch sits near a decision boundary."""
     g = np.load(os.path.join(GOLD, name))
-    cfg = mk()
+    cfg, plan = mk()
+    n = g["decision"].size
+    again = ref_f64.run(plan, g["iq"], n, L=int(g["L"]))
+    assert np.allclose(again["spectrum"], g["spectrum_f64"], rtol=1e-12, atol=0)
+    assert np.allclose(again["features"], g["features_f64"], rtol=1e-12, atol=0)
+    assert np.array_equal(again["decision"], g["decision"])
+    assert (g["margin"] > (1e-3 if plan.decide == "ann" else 1e-4)).all()
+    if plan.decide == "ann":
+        assert np.array_equal(g["decision"], g["picks"])   # decisions = the channels the input drives
+
+
+@pytest.mark.parametrize("name,mk", CASES)
+def test_oracle_matches_independent_golden(built, name, mk):
+    g = np.load(os.path.join(GOLD, name))
+    cfg, _ = mk()
     n = g["decision"].size
     got = orc.run(cfg, g["iq"], n, L=int(g["L"]), want_spectrum=True)
-    assert np.allclose(got["spectrum"], g["spectrum"], rtol=1e-6, atol=0)
-    assert np.allclose(got["features"], g["features"], rtol=1e-6, atol=0)
-    assert np.array_equal(got["decision"], g["decision"])
-    assert np.array_equal(got["occupancy"], g["occupancy"])
-    assert per_bin_err(got["spectrum"], g["spectrum_f64"]) < 1e-5
+    check_against_golden(got, g, cfg, FLOOR_ORACLE)
+
+
+def test_literal_reference_epoch_matches_independent_golden(built):
+    """crn_oracle_ref_epoch is the line-by-line form of CE_Predictive_Node.cpp:146-289 (fixed arrays of
+    512, the five loops as written); it must land on the float64 values too."""
+    for name in ("ref512_L364.npz", "ref512_L512.npz"):
+        g = np.load(os.path.join(GOLD, name))
+        L = int(g["L"])
+        for e in range(g["decision"].size):
+            r = orc.ref_epoch(g["iq"][e * 10 * L * 2:(e + 1) * 10 * L * 2], L)
+            assert r["decision"] == g["decision"][e]
+            assert np.allclose(r["features"], g["features_f64"][e], rtol=1e-5, atol=0)
+            assert np.abs(r["ann_out"] - g["ann_out_f64"][e]).max() < 1e-6
+            assert r["tx_freq"] == (ref_f64.TX_FREQ[int(g["decision"][e])] or 0.0)
 
 
 def test_oracle_ann_table(built):
     g = np.load(os.path.join(GOLD, "ann_table.npz"))
+    assert g["decision"].size >= 64
     for f, o, d in zip(g["features"], g["ann_out"], g["decision"]):
         dd, oo = orc.ann(f)
-        assert dd == d and np.allclose(oo, o, rtol=1e-12, atol=1e-300)
+        assert dd == d and np.abs(oo - o).max() < 1e-9, (f, oo, o)   # glibc exp vs numpy exp: ulps
+
+
+def _bisect_crossing(out_of, channel, idle, nf):
+    def out(v):
+        f = np.array([nf, idle, idle, idle], dtype=np.float32)
+        f[channel] = v
+        return out_of(f)[channel - 1]
+    lo, hi = idle, 1e4
+    assert out(lo) < 0.8 <= out(hi)
+    for _ in range(100):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if out(mid) < 0.8 else (lo, mid)
+    return hi
+
+
+@pytest.mark.parametrize("impl", ["ref_f64", "oracle"])
+def test_survey_appendix_c_values(built, impl):
+    """The survey's ANN response probe (typed into kat.json from the document):
+    all-zero and idle outputs, the feature level at which each channel's output crosses 0.8
+    (~231 / 25 / 45), and O ~ 0.9993-0.9995 with the other outputs < 3e-4 at feature 866."""
+    k = json.load(open(os.path.join(GOLD, "kat.json")))
+    c = k["appendix_c"]
+    out_of = (lambda f: ref_f64.ann(f)) if impl == "ref_f64" else (lambda f: orc.ann(f)[1])
+    assert np.allclose(out_of(np.zeros(4, np.float32)), k["all_zero"]["ann_out"], rtol=2e-3)
+    assert np.allclose(out_of(np.array(c["idle"]["features"], np.float32)), c["idle"]["ann_out"], rtol=5e-2)
+    nf, idle = c["idle"]["features"][0], c["idle"]["features"][1]
+    for ch in (1, 2, 3):
+        x = _bisect_crossing(out_of, ch, idle, nf)
+        assert abs(x - c["crossing"][str(ch)]) <= 0.5, (ch, x)       # the survey rounds to integers
+        f = np.array([nf, idle, idle, idle], np.float32)
+        f[ch] = c["occupied_feature"]
+        o = out_of(f)
+        lo, hi = c["occupied_output_range"]
+        assert lo - 5e-5 <= o[ch - 1] <= hi + 5e-5, (ch, o)
+        assert all(o[j] < c["others_below"] + 2e-5 for j in range(3) if j != ch - 1), (ch, o)
 
 
 def test_hand_derived_known_answers(built):
     k = json.load(open(os.path.join(GOLD, "kat.json")))
     n = np.arange(k["n"])
+    plan = ref_f64.plan_reference()
     for row in k["tone_rows"]:
         iq = np.tile(np.exp(2j * np.pi * row["bin"] * n / k["n"]).astype(np.complex64), k["frames"]).view(np.float32)
         r = orc.ref_epoch(iq, k["n"])
+        r64 = ref_f64.run(plan, iq, 1)
         for b in range(4):
             want = row["feature"] if row["band"] == b else 0.0
             assert abs(r["features"][b] - want) <= 1e-5 * max(want, 100.0), (row, b)
+            assert abs(r64["features"][0, b] - want) <= 1e-5 * max(want, 100.0), (row, b)
     z = orc.ref_epoch(np.zeros(k["frames"] * k["n"] * 2, np.float32), k["n"])
     assert z["decision"] == k["all_zero"]["decision"]
     assert np.allclose(z["ann_out"], k["all_zero"]["ann_out"], rtol=2e-3)
 
 
+def test_cfg_helpers_describe_the_independent_plans(built):
+    """crn_cfg_reference / _energy_scaled / _welch (product, csrc/crn_cfg.cpp) against ref_f64's plans
+    (typed independently from SURVEY.md Appendix A): band runs in summation order, thresholds, weights."""
+    def runs_of(cfg):
+        runs = {}
+        for s in range(cfg.n_segs):
+            g = cfg.segs[s]
+            runs.setdefault(g.band, []).append((g.lo, g.hi))
+        return {b: tuple(v) for b, v in runs.items()}
+
+    for cfg, plan in ((cs.cfg_reference(), ref_f64.plan_reference()),
+                      (cs.cfg_energy_scaled(1024, 4.0), ref_f64.plan_energy_scaled(1024, 4.0)),
+                      (cs.cfg_energy_scaled(4096, 4.0), ref_f64.plan_energy_scaled(4096, 4.0)),
+                      (cs.cfg_welch(4096, 8, 64), ref_f64.plan_welch(4096, 8, 64, [np.inf] * 64))):
+        assert (cfg.fft_len, cfg.frames_per_epoch, cfg.hop) == (plan.n, plan.k, plan.hop or plan.n)
+        assert runs_of(cfg) == {b: tuple(rr) for b, rr in plan.runs.items()}
+        assert cfg.mode == (cs.MODE_REF_MAG if plan.mode == "mag" else cs.MODE_ENERGY)
+        assert cfg.ref_band == plan.ref_band
+        if plan.decide == "threshold":
+            assert np.array_equal(np.array(cfg.thresh[:plan.n_bands], np.float32), np.array(plan.thresh, np.float32))
+        assert np.array_equal(np.array([list(r) for r in cfg.ann_w_ih]), ref_f64.W_IH)
+        assert np.array_equal(np.array([list(r) for r in cfg.ann_w_ho]), ref_f64.W_HO)
+        assert cfg.ann_threshold == ref_f64.ANN_THRESHOLD
+    ref = cs.cfg_reference()
+    assert [ref.tx_freq_for_decision[d] for d in (1, 2, 3)] == [ref_f64.TX_FREQ[d] for d in (1, 2, 3)]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,mk", CASES)
-def test_gpu_matches_golden(built, name, mk):
+def test_gpu_matches_independent_golden(built, name, mk):
     g = np.load(os.path.join(GOLD, name))
-    cfg = mk()
+    cfg, _ = mk()
     n = g["decision"].size
     s = cs.Sensor(cfg)
     got = s.run_host(g["iq"], n, L=int(g["L"]), want_spectrum=True)
     s.close()
-    assert per_bin_err(got["spectrum"], g["spectrum_f64"]) < 1e-5
-    assert np.allclose(got["features"], g["features"], rtol=1e-5, atol=0)
-    assert np.array_equal(got["decision"], g["decision"])
-    assert np.array_equal(got["occupancy"], g["occupancy"])
-    if cfg.decide == cs.DECIDE_ANN:
-        assert np.abs(got["ann_out"] - g["ann_out"]).max() < 1e-6
+    check_against_golden(got, g, cfg, floor_gpu(cfg))
 
 
 @pytest.mark.gpu
@@ -84,3 +216,31 @@ def test_gpu_known_answers(built):
         for b in range(4):
             want = row["feature"] if row["band"] == b else 0.0
             assert abs(got["features"][i, b] - want) <= 1e-5 * max(want, 100.0), (row, b)
+
+
+@pytest.mark.gpu
+def test_gpu_ann_table_through_the_kernel(built):
+    """The fused network on the device against the float64 table: each table row's four features are
+    produced by a crafted epoch (on-bin tones whose amplitudes give exactly those band sums), so the
+    kernel's own fp64 tail — not a host computation — is what is compared."""
+    g = np.load(os.path.join(GOLD, "ann_table.npz"))
+    feats = g["features"]
+    n = np.arange(512)
+    centre = {0: 304, 1: 8, 2: 70, 3: 200}          # one bin inside NF, CH1, CH2, CH3
+    frames = []
+    for f in feats:
+        x = np.zeros(512, np.complex128)
+        for b in range(4):
+            x += (np.sqrt(float(f[b])) / 512.0) * np.exp(2j * np.pi * centre[b] * n / 512)   # |X| = sqrt(F) -> M^2 = F
+        frames.append(np.tile(x, 10))
+    iq = np.stack(frames).astype(np.complex64).view(np.float32).ravel()
+    s = cs.Sensor(cs.cfg_reference())
+    got = s.run_host(iq, len(feats))
+    s.close()
+    # the crafted features only approximate the table's (fp32 tones): feed what the kernel measured to the f64 net
+    want = ref_f64.ann(got["features"].astype(np.float64))
+    assert np.abs(got["ann_out"] - want).max() < 1e-6
+    near = np.abs(want - 0.8).min(axis=1) < 1e-3
+    assert np.array_equal(got["decision"][~near], ref_f64.cascade(want)[~near])
+    rel = np.abs(got["features"] - feats) / np.maximum(feats, 1e-3)
+    assert np.median(rel) < 1e-3      # the crafted epochs do land on the table's operating points

@@ -1,7 +1,13 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and float64.
 
 Tolerances (DESIGN.md "Parity"):
-  per-bin   |E - E64| <= 1e-5 * max(E64, 1e-2 * mean_k E64)   E = K-frame average per bin
+  per-bin   |E - E64| <= 1e-5 * max(E64, floor * mean_k E64)   E = K-frame average per bin.
+            BASELINE.md §2 / SURVEY.md §8(c) state floor = 1e-3.  Measured on the GPU
+            (test_per_bin_error_at_the_stated_floor, profiles/r02_per_bin_error_at_floor.txt): the HIP path meets
+            1e-5 at that floor for N <= 1024 (6.9e-6 / 8.2e-6) and is held to it there; at N = 2048 / 4096 it
+            measures 1.4e-5 / 2.1e-5 (the radix-2 CPU restatement: 1.8e-5 / 3.6e-5) — fp32 rounding in the
+            cancelling adds next to a +36 dB tone, whatever the factorisation — so those sizes keep
+            floor = 1e-2 (GPU 3.2e-6 / 5.0e-6), with the 1e-3 figures bounded and compared with the oracle's.
   features  relative 1e-5 against the oracle
   decisions bit-exact; every epoch in these fixtures sits outside the near-threshold margin
             (|O - 0.8| > 1e-3 for the ANN, |E/thr - 1| > 1e-4 for thresholds), which is asserted.
@@ -16,7 +22,21 @@ import signals
 pytestmark = pytest.mark.gpu
 
 PER_BIN_TOL = 1e-5
-FLOOR = 1e-2
+FLOOR = 1e-2          # default floor (any size); floor_for(cfg) gives the stated 1e-3 where the HIP path meets it
+
+
+def floor_for(cfg):
+    """The stated floor where the bar is stated and the HIP path meets it (the K = 10 rectangular
+    configurations at N <= 1024); 1e-2 * mean elsewhere (larger N, windowed / short-K variants)."""
+    stated = cfg.fft_len <= 1024 and cfg.window == cs.WINDOW_RECT and cfg.frames_per_epoch >= 10
+    return 1e-3 if stated else 1e-2
+
+
+# Bounds on the HIP path's error AT THE STATED FLOOR (1e-3 * mean), energy mode, measured 6.9e-6 / 8.2e-6 /
+# 1.4e-5 / 2.1e-5; and at any floor in magnitude mode (the floor never bites there), measured 3.4e-6 .. 1.0e-5.
+STATED_FLOOR_BOUND = {512: 1e-5, 1024: 1e-5, 2048: 2e-5, 4096: 3e-5}
+MAG_BOUND = {512: 1e-5, 1024: 1e-5, 2048: 1e-5, 4096: 1.5e-5}
+FLOOR_ORACLE = 1e-2   # what the radix-2 restatement is held to (tests/test_golden.py)
 FEATURE_TOL = 1e-5
 
 
@@ -25,8 +45,9 @@ def per_bin_err(spec, truth, floor=FLOOR):
     return (np.abs(spec - truth) / np.maximum(truth, fl)).max()
 
 
-def check_against_oracle(cfg, iq, n_epochs, L=None, got=None, floor=FLOOR):
+def check_against_oracle(cfg, iq, n_epochs, L=None, got=None, floor=None):
     s = None
+    floor = floor_for(cfg) if floor is None else floor
     if got is None:
         s = cs.Sensor(cfg)
         got = s.run_host(iq, n_epochs, L=L, want_spectrum=True)
@@ -36,6 +57,7 @@ def check_against_oracle(cfg, iq, n_epochs, L=None, got=None, floor=FLOOR):
     assert per_bin_err(got["spectrum"], truth, floor) < PER_BIN_TOL
     # ... and never further from float64 than the CPU restatement is (plus rounding headroom)
     assert per_bin_err(got["spectrum"], truth, floor) < 2.0 * per_bin_err(want["spectrum"], truth, floor) + 2e-6
+    assert per_bin_err(want["spectrum"], truth, max(floor, FLOOR_ORACLE)) < 2 * PER_BIN_TOL
     denom = np.maximum(np.abs(want["features"]), 1e-30)
     assert (np.abs(got["features"] - want["features"]) / denom).max() < FEATURE_TOL
     if cfg.decide == cs.DECIDE_ANN:
@@ -50,6 +72,43 @@ def check_against_oracle(cfg, iq, n_epochs, L=None, got=None, floor=FLOOR):
     assert np.array_equal(got["decision"], want["decision"])
     assert np.array_equal(got["occupancy"], want["occupancy"])
     return got, want
+
+
+def test_per_bin_error_at_the_stated_floor(built):
+    """report, and bound, the HIP path's own per-bin error against float64 at the
+    stated floor 1e-3 * mean(E) — next to the CPU restatement's — for every size and both modes, on
+    epochs with and without a driven channel (an occupied band raises mean(E), which is what makes the
+    floor bite on the noise-only bins)."""
+    import os
+    rows = []
+    lines = ["N mode  gpu@1e-3  gpu@1e-2  oracle@1e-3  oracle@1e-2   (max over bins and epochs of |E - E64| / max(E64, floor * mean E64))"]
+    for n in (512, 1024, 2048, 4096):
+        for mode in ("energy", "mag"):
+            cfg = cs.cfg_energy_scaled(n, 4.0)
+            if mode == "mag":
+                cfg.mode = cs.MODE_REF_MAG
+            n_epochs = 12
+            iq, _ = signals.make_epochs(cfg, n_epochs, seed=4242 + n, picks=[0, 1, 2, 3] * 3)
+            s = cs.Sensor(cfg)
+            got = s.run_host(iq, n_epochs, want_spectrum=True)
+            s.close()
+            want = orc.run(cfg, iq, n_epochs, want_spectrum=True)
+            truth = signals.spectrum_f64(cfg, iq, n_epochs)
+            g3, g2 = per_bin_err(got["spectrum"], truth, 1e-3), per_bin_err(got["spectrum"], truth, 1e-2)
+            o3, o2 = per_bin_err(want["spectrum"], truth, 1e-3), per_bin_err(want["spectrum"], truth, 1e-2)
+            lines.append(f"{n} {mode}  {g3:.3g}  {g2:.3g}  {o3:.3g}  {o2:.3g}")
+            rows.append((n, mode, g3, g2, o3, o2, lines[-1]))
+    print("\n".join(lines))
+    out_dir = os.environ.get("CRN_EVIDENCE_DIR")
+    if out_dir:
+        open(os.path.join(out_dir, "per_bin_error_at_floor.txt"), "w").write("\n".join(lines) + "\n")
+    for n, mode, g3, g2, o3, o2, line in rows:
+        assert g3 <= o3 + 1e-6 and g2 <= o2 + 1e-6, line   # never further from float64 than radix-2 fp32
+        if mode == "energy":
+            assert g2 < PER_BIN_TOL, line                  # the bar at floor 1e-2: every size
+            assert g3 < STATED_FLOOR_BOUND[n], line        # the stated floor: met (1e-5) for N <= 1024, bounded above it
+        else:
+            assert g3 < MAG_BOUND[n], line
 
 
 @pytest.mark.parametrize("L", [512, 364, 363, 100])
@@ -356,7 +415,7 @@ def test_frames_per_epoch_edge_cases(built, n, K):
     # The 1e-5 per-bin bar is stated for the K = 10 average.  Without averaging, a bin at 1 % of the
     # mean energy holds |X| ~ 0.1 rms, and the ~1e-6 rms absolute error of ANY fp32 transform is
     # already 2e-5 of it: for K < 4 the floor is 10 % of the mean.
-    check_against_oracle(cfg, iq, n_epochs, floor=FLOOR if K >= 4 else 1e-1)
+    check_against_oracle(cfg, iq, n_epochs, floor=floor_for(cfg) if K >= 4 else 1e-1)
 
 
 def test_maximum_band_table(built):
@@ -447,7 +506,7 @@ def test_randomised_configurations(built, seed):
     s.close()
     want = orc.run(cfg, iq, n_epochs, L=L, want_spectrum=True)
     truth = signals.spectrum_f64(cfg, iq, n_epochs, L=L)
-    floor = FLOOR if cfg.frames_per_epoch >= 4 else 1e-1
+    floor = floor_for(cfg) if cfg.frames_per_epoch >= 4 else 1e-1
     assert per_bin_err(got["spectrum"], truth, floor) < 2.0 * per_bin_err(want["spectrum"], truth, floor) + 2e-6
     assert np.allclose(got["features"], want["features"], rtol=2e-5, atol=0)
     margin = np.abs(want["features"] / np.array(cfg.thresh[:nb], np.float32)[None, :] - 1) > 1e-4
@@ -539,7 +598,7 @@ def test_welch_stream_across_epochs(built, n, K, n_epochs, epw):
     got = s.run_host(iq, n_epochs, want_spectrum=True)
     want = orc.run(cfg, iq, n_epochs, want_spectrum=True)
     truth = signals.spectrum_f64(cfg, iq, n_epochs)
-    floor = FLOOR if K >= 4 else 1e-1
+    floor = floor_for(cfg) if K >= 4 else 1e-1
     assert per_bin_err(got["spectrum"], truth, floor) < PER_BIN_TOL
     assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
     assert np.array_equal(got["occupancy"], want["occupancy"])

@@ -4,7 +4,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 V=${V:-3}
 EXTRA=${EXTRA:-}
-OUT=$R/gpurun_out/pmc_v$V
+TAG=${TAG:-v$V}
+OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run() { # name counters...
   name=$1; shift
