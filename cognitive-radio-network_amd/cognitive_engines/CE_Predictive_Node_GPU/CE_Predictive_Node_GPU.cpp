@@ -1,6 +1,6 @@
 // CE_Predictive_Node_GPU.cpp — see the header.  Control flow follows the reference's execute()
 // (cognitive_engines/CE_Predictive_Node/CE_Predictive_Node.cpp:54-292) statement for statement;
-// the arithmetic of lines 148-261 is one call into libcrnsense per epoch.
+// the arithmetic of lines 148-261 is one launch of libcrnsense per epoch.
 #include "CE_Predictive_Node_GPU.hpp"
 
 #include <math.h>
@@ -9,7 +9,15 @@
 #include <string.h>
 #include <unistd.h>
 
-// constructor (reference: CE_Predictive_Node.cpp:18-46)
+static void die_crn(void) {
+  // the reference's convention for unrecoverable set-up errors (src/crts.cpp:111-115)
+  fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
+  exit(EXIT_FAILURE);
+}
+
+// constructor (reference: CE_Predictive_Node.cpp:18-46).  Everything the engine will ever
+// allocate — tables, device batch buffers, pinned staging, the HIP stream — is allocated here,
+// and the kernels are loaded by one launch over zeros: execute() never allocates.
 CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, ExtensibleCognitiveRadio *_ECR) {
   ECR = _ECR;
 
@@ -17,13 +25,14 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   config = 0;
   sensor = NULL;
   ring = NULL;
-  async_mode = 0;
+  async_mode = 1;
   wall_clock_gate = true;
   verbose = 1;
   frame_len = 0;
   sensing_on = 0;
   decision = 0;
   epochs_closed = 0;
+  packets_dropped = 0;
   memset(features, 0, sizeof(features));
   memset(outputs, 0, sizeof(outputs));
 
@@ -35,7 +44,7 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   optind = 1;
   while ((o = getopt(argc, argv, "a:d:g:v:")) != EOF) {
     switch (o) {
-    case 'a': async_mode = atoi(optarg); break;            // 1: enqueue + poll through the ingest ring
+    case 'a': async_mode = atoi(optarg); break;            // 0: decide inside the K-th execute()
     case 'd': cfg.device = atoi(optarg); break;           // HIP device ordinal
     case 'g': wall_clock_gate = atoi(optarg) != 0; break;  // 0: sense continuously
     case 'v': verbose = atoi(optarg); break;
@@ -48,11 +57,15 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   sense_time_us = tv.tv_usec;
 
   // replaces memset of the three buffers + fft_create_plan (.cpp:36-45)
-  staging.assign((size_t)cfg.frames_per_epoch * cfg.fft_len, std::complex<float>(0.f, 0.f));
-  if (crn_sense_create(&cfg, &sensor) != CRN_OK) {
-    // the reference's convention for unrecoverable set-up errors (src/crts.cpp:111-115)
-    fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
-    exit(EXIT_FAILURE);
+  if (crn_sense_create(&cfg, &sensor) != CRN_OK) die_crn();
+  if (crn_sense_reserve_host(sensor, 1, 0) != CRN_OK) die_crn();  // scratch + pinned staging + kernel load
+  if (async_mode) {
+    // one stream, one epoch per batch; sized for full-length packets, the actual UHD packet length is
+    // known only when the rx worker starts (src/extensible_cognitive_radio.cpp:1263-1265)
+    if (crn_ingest_create(sensor, 1, cfg.fft_len, 1, &ring) != CRN_OK) die_crn();
+    frame_len = cfg.fft_len;
+  } else {
+    staging.assign((size_t)cfg.frames_per_epoch * cfg.fft_len, std::complex<float>(0.f, 0.f));
   }
 }
 
@@ -120,7 +133,7 @@ void CE_Predictive_Node_GPU::execute() {
     sensing_on = 1;
   }
 
-  // asynchronous path: a decision launched by an earlier call may have landed
+  // a decision launched by an earlier call may have landed (one event query, never a wait)
   if (ring) {
     crn_epoch_result r;
     int32_t n = 0;
@@ -135,24 +148,25 @@ void CE_Predictive_Node_GPU::execute() {
     int L = ECR->ce_usrp_rx_buffer_length;
     if (L > N) L = N;
     if (L < 1) return;
-    if (async_mode && !ring) {
-      // one stream, one epoch per batch: the launch happens inside the K-th push, nothing waits
-      if (crn_ingest_create(sensor, 1, L, 1, &ring) != CRN_OK) {
-        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
-        exit(EXIT_FAILURE);
-      }
-    }
     if (ring) {
-      if (L != frame_len && fft_counter != 0) return;  // UHD packet size is constant in practice
-      frame_len = L;
-      if (crn_ingest_push(ring, 0, reinterpret_cast<const float *>(ECR->ce_usrp_rx_buffer)) != CRN_OK) {
-        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
-        exit(EXIT_FAILURE);
+      if (L != frame_len) {              // UHD packet size is constant in practice: once, at the first packet
+        if (fft_counter != 0) return;    // never inside an epoch
+        const int rc = crn_ingest_set_packet_len(ring, L);
+        if (rc == CRN_ERR_BUSY) { packets_dropped++; return; }
+        if (rc != CRN_OK) die_crn();
+        frame_len = L;
       }
+      // one copy of the packet into its pinned slot; the K-th one also enqueues H2D + kernel + D2H
+      const int rc = crn_ingest_push(ring, 0, reinterpret_cast<const float *>(ECR->ce_usrp_rx_buffer));
+      if (rc == CRN_ERR_BUSY) {          // both batch buffers on the GPU: this packet is skipped, like a
+        packets_dropped++;               // frame the reference's CE thread was not ready for
+        return;
+      }
+      if (rc != CRN_OK) die_crn();
       if (++fft_counter == K) {
         ECR->set_ce_sensing(0);  // .cpp:159; the decision is reported by a later execute()
         sensing_on = 0;
-        fft_counter = 0;
+        fft_counter = 0;         // .cpp:287-288
       }
       return;
     }
@@ -177,10 +191,8 @@ void CE_Predictive_Node_GPU::execute() {
       out.ann_out = out3;
       out.decision = &d;
       if (crn_sense_run_host(sensor, reinterpret_cast<const float *>(staging.data()), 1, frame_len, 0, &out) !=
-          CRN_OK) {
-        fprintf(stderr, "CE_Predictive_Node_GPU: %s\n", crn_last_error());
-        exit(EXIT_FAILURE);
-      }
+          CRN_OK)
+        die_crn();
       report(feat, out3, d);
 
       fft_counter = 0;  // .cpp:287-288 (fft_avg lives on the device and starts from zero each launch)

@@ -1,7 +1,7 @@
 """ctypes binding of libcrnsense's C ABI (include/crn_sense.h).
 
 Plumbing for tests/, bench.py and __graft_entry__.py only: the product is the C-ABI shared
-library and the C++ engine in host/; nothing here computes.  There is no CPU fallback: loading
+library and the C++ engine in cognitive_engines/CE_Predictive_Node_GPU/; nothing here computes.  There is no CPU fallback: loading
 fails loudly when libcrnsense.so has not been built, and crn_sense_create fails when no GPU is
 visible.
 """
@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense.so")  # env override: A/B builds
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
-CRN_ABI_VERSION = 1
+CRN_ABI_VERSION = 2
+CRN_ERR_BUSY = -5
 CRN_MAX_BANDS = 80
 CRN_MAX_SEGS = 160
 
@@ -27,7 +28,8 @@ EXPORTS = [
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
-    "crn_ingest_destroy",
+    "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
+    "crn_sense_reserve_host",
     "crn_last_error", "crn_abi_version",
 ]
 
@@ -119,6 +121,10 @@ def lib():
         L.crn_ingest_poll.argtypes = [C.c_void_p, C.POINTER(EpochResult), C.c_int32, C.POINTER(C.c_int32)]
         L.crn_ingest_drain.argtypes = [C.c_void_p]
         L.crn_ingest_destroy.argtypes = [C.c_void_p]
+        L.crn_ingest_set_packet_len.argtypes = [C.c_void_p, C.c_int32]
+        L.crn_ingest_wait.argtypes = [C.c_void_p]
+        L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         _lib = L
     return _lib
 
@@ -177,6 +183,9 @@ class Sensor:
             self.close()
         except Exception:
             pass
+
+    def reserve_host(self, max_epochs, want_spectrum=False):
+        check(lib().crn_sense_reserve_host(self._h, max_epochs, int(want_spectrum)), "crn_sense_reserve_host")
 
     def set_variant(self, v):
         check(lib().crn_sense_set_variant(self._h, v), "crn_sense_set_variant")
@@ -264,8 +273,25 @@ class Ingest:
         check(lib().crn_ingest_create(sensor._h, n_streams, samples_per_packet, epochs_per_batch,
                                       C.byref(self._g)), "crn_ingest_create")
 
-    def push(self, stream, packet):
-        check(lib().crn_ingest_push(self._g, stream, packet.ctypes.data), "crn_ingest_push")
+    def push(self, stream, packet, block=True):
+        """block=True: on CRN_ERR_BUSY wait for a free buffer and push again (tests, tools);
+        block=False: returns False when the packet was refused (what an engine's execute() does)."""
+        rc = lib().crn_ingest_push(self._g, stream, packet.ctypes.data)
+        while rc == CRN_ERR_BUSY and block:
+            check(lib().crn_ingest_wait(self._g), "crn_ingest_wait")
+            rc = lib().crn_ingest_push(self._g, stream, packet.ctypes.data)
+        if rc == CRN_ERR_BUSY:
+            return False
+        check(rc, "crn_ingest_push")
+        return True
+
+    def set_packet_len(self, L):
+        check(lib().crn_ingest_set_packet_len(self._g, L), "crn_ingest_set_packet_len")
+
+    def dropped(self):
+        n = C.c_int64()
+        check(lib().crn_ingest_dropped(self._g, C.byref(n)), "crn_ingest_dropped")
+        return n.value
 
     def flush(self):
         check(lib().crn_ingest_flush(self._g), "crn_ingest_flush")

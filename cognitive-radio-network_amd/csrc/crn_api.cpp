@@ -314,6 +314,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
+  HIP_TRY(hipSetDevice(h->cfg.device));  // a NULL stream / a launch follows the calling thread's current device
   // a workgroup addresses its window with 32-bit byte offsets
   if ((64 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * 8 >= ((int64_t)1 << 31))
     return crn::fail(CRN_ERR_ARG, "epoch_stride too large (a workgroup window must stay below 2 GiB)");
@@ -427,6 +428,22 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   return CRN_OK;
 }
 
+int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t want_spectrum) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  if (max_epochs < 1) return crn::fail(CRN_ERR_ARG, "max_epochs < 1");
+  const crn_cfg &c = h->cfg;
+  // a run of zeros at the largest size: allocates the scratch slab and the pinned result staging,
+  // loads the code object and sets the kernel's LDS attribute
+  const int64_t stride = (int64_t)c.frames_per_epoch * c.hop;
+  const size_t n_samples = (size_t)(max_epochs * stride + (c.fft_len - c.hop));
+  std::vector<float> zeros(n_samples * 2, 0.f);
+  std::vector<float> feat((size_t)max_epochs * c.n_bands), spec(want_spectrum ? (size_t)max_epochs * c.fft_len : 0);
+  crn_out o{};
+  o.features = feat.data();
+  o.spectrum = want_spectrum ? spec.data() : nullptr;
+  return crn_sense_run_host(h, zeros.data(), max_epochs, c.fft_len, 0, &o);
+}
+
 int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, int32_t samples_per_frame,
                            int64_t frame_stride, float *d_out, void *stream) {
   if (!h || !d_in || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
@@ -476,6 +493,7 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
     if (n_epochs % sc->n_streams != 0) return crn::fail(CRN_ERR_ARG, "n_streams must divide n_epochs");
   }
   const crn_cfg &c = h->cfg;
+  HIP_TRY(hipSetDevice(c.device));
   crn::SynthParams p{};
   p.iq = reinterpret_cast<float2 *>(d_iq);
   p.n_epochs = n_epochs;

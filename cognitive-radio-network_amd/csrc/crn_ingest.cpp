@@ -1,14 +1,28 @@
 // crn_ingest.cpp — packet ingest ring (include/crn_sense.h, "ingest ring").
 //
 // Host-side counterpart of the ECR's rx -> CE hand-off
-// (reference: src/extensible_cognitive_radio.cpp:1310-1324): per-stream staging of K packets,
-// complete epochs packed into one of two pinned batch buffers, asynchronous H2D + sensing kernel +
-// D2H on a private HIP stream, completion detected with an event so the caller never blocks.
+// (reference: src/extensible_cognitive_radio.cpp:1310-1324).  Two pinned batch buffers of C epoch
+// slots each.  A stream that starts an epoch is given the next free slot of the batch being filled
+// and every packet is copied ONCE, straight into its place in that pinned slot; when enough slots
+// are complete the batch is handed to the ring's launcher thread, which makes every HIP call
+// (H2D -> sensing kernel -> D2H on a private stream, completion by event) and files the results;
+// filling continues in the other buffer.
+//
+// Threads: the caller's thread (the CE thread: crn_ingest_push / _poll run inside execute(), with
+// CE_mutex held) touches pinned memory, a few counters, and a mutex for the hand-off queues — never
+// the HIP runtime, never the allocator on the packet path.  When the buffer it would have to fill is
+// still on the GPU the packet is refused with CRN_ERR_BUSY (the reference's own hand-off drops
+// frames the CE thread is not ready for).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/crn_sense.h"
@@ -23,20 +37,26 @@
 
 namespace {
 
-struct SlotTag {
-  int32_t stream;
+struct Slot {
+  int32_t stream;  // -1: a hole (its epoch moved on to the next batch; nothing to report)
   int64_t seq;
+  int npk;         // packets staged
 };
 
+enum : int { kFree = 0, kQueued = 1 };  // Batch::state: owned by the caller / by the launcher thread
+
 struct Batch {
-  float *h_iq = nullptr;        // pinned [B][K][L] interleaved
+  float *h_iq = nullptr;        // pinned [C][K][cap] interleaved
   float *d_iq = nullptr;
   char *h_res = nullptr;        // pinned results: features | ann | decision | occupancy
   char *d_res = nullptr;
   hipEvent_t done = nullptr;
-  std::vector<SlotTag> tags;    // slot -> (stream, seq) of the batch as launched / being filled
-  int filled = 0;               // complete epochs staged
-  bool in_flight = false;
+  std::vector<Slot> slots;      // [C]
+  int assigned = 0;             // slots handed to streams, in order of epoch start
+  int complete = 0;             // of which hold all K packets
+  int launched = 0;             // slots of the launch handed to the launcher thread
+  int L = 0;                    // packet length of that launch
+  std::atomic<int> state{kFree};
 };
 
 }  // namespace
@@ -44,16 +64,25 @@ struct Batch {
 struct crn_ingest {
   crn_handle *h = nullptr;
   crn_cfg cfg;
-  int n_streams = 0, L = 0, B = 0, K = 0;
-  size_t epoch_floats = 0;                 // K * L * 2
+  int n_streams = 0, L = 0, cap = 0, B = 0, C = 0, K = 0;
+  size_t epoch_floats = 0;                 // K * L * 2 (dense: the kernel is run with samples_per_frame = L)
   size_t off_ann = 0, off_dec = 0, off_occ = 0, res_bytes = 0;
   hipStream_t stream = nullptr;
   Batch batch[2];
-  int fill = 0;                            // batch being filled
-  std::vector<std::vector<float>> staging; // per stream: K packets of the running epoch
-  std::vector<int> packets;                // per stream: packets staged
-  std::vector<int64_t> seq;                // per stream: epochs completed
+  // ---- caller-thread state ----
+  int fill = 0;                            // batch being filled; every open slot lives in it
+  std::vector<int> open_slot;              // per stream: its slot in batch[fill], -1 = between epochs
+  std::vector<int64_t> seq;                // per stream: epochs started
+  int64_t dropped = 0;                     // packets refused with CRN_ERR_BUSY
+  // ---- shared with the launcher thread (under mu) ----
+  std::mutex mu;
+  std::condition_variable cv_work, cv_free;
+  std::deque<int> work;                    // batches to launch, in order
   std::deque<crn_epoch_result> ready;
+  int err_code = CRN_OK;                   // first failure on the launcher thread, reported by the next call
+  std::string err_msg;
+  bool stop = false;
+  std::thread launcher;
 };
 
 // defined in crn_api.cpp
@@ -63,51 +92,165 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Move the results of a finished batch into the ready queue.
-void harvest(crn_ingest *g, Batch &b) {
+// ---- launcher thread -------------------------------------------------------------------------
+
+// H2D + kernel + D2H + event for one batch; returns an error message or "".
+std::string enqueue(crn_ingest *g, Batch &b) {
+  const size_t epoch_floats = (size_t)g->K * b.L * 2;
+  hipError_t e = hipMemcpyAsync(b.d_iq, b.h_iq, (size_t)b.launched * epoch_floats * sizeof(float), hipMemcpyHostToDevice, g->stream);
+  if (e != hipSuccess) return std::string("hipMemcpyAsync(H2D): ") + hipGetErrorString(e);
+  crn_out out;
+  out.features = reinterpret_cast<float *>(b.d_res);
+  out.ann_out = reinterpret_cast<double *>(b.d_res + g->off_ann);
+  out.decision = reinterpret_cast<int32_t *>(b.d_res + g->off_dec);
+  out.occupancy = reinterpret_cast<uint8_t *>(b.d_res + g->off_occ);
+  out.spectrum = nullptr;
+  if (crn_sense_run_device(g->h, b.d_iq, b.launched, b.L, 0, &out, g->stream) != CRN_OK) return crn_last_error();
+  e = hipMemcpyAsync(b.h_res, b.d_res, g->res_bytes, hipMemcpyDeviceToHost, g->stream);
+  if (e == hipSuccess) e = hipEventRecord(b.done, g->stream);
+  if (e != hipSuccess) return std::string("hipMemcpyAsync(D2H) / hipEventRecord: ") + hipGetErrorString(e);
+  return "";
+}
+
+void collect(crn_ingest *g, const Batch &b, std::vector<crn_epoch_result> *out) {
   const int nb = g->cfg.n_bands;
   const float *feat = reinterpret_cast<const float *>(b.h_res);
   const double *ann = reinterpret_cast<const double *>(b.h_res + g->off_ann);
   const int32_t *dec = reinterpret_cast<const int32_t *>(b.h_res + g->off_dec);
   const uint8_t *occ = reinterpret_cast<const uint8_t *>(b.h_res + g->off_occ);
-  for (int s = 0; s < b.filled; s++) {
+  for (int s = 0; s < b.launched; s++) {
+    if (b.slots[s].stream < 0) continue;
     crn_epoch_result r;
     std::memset(&r, 0, sizeof(r));
-    r.stream = b.tags[s].stream;
-    r.epoch_seq = b.tags[s].seq;
+    r.stream = b.slots[s].stream;
+    r.epoch_seq = b.slots[s].seq;
     r.decision = dec[s];
     if (g->cfg.decide == CRN_DECIDE_ANN) std::memcpy(r.ann_out, ann + 3 * s, 3 * sizeof(double));
     std::memcpy(r.features, feat + (size_t)s * nb, nb * sizeof(float));
     std::memcpy(r.occupancy, occ + (size_t)s * nb, nb);
-    g->ready.push_back(r);
+    out->push_back(r);
   }
-  b.filled = 0;
-  b.in_flight = false;
 }
 
+// Give a batch back to the caller's thread (mu held).
+void release_batch(crn_ingest *g, Batch &b) {
+  b.assigned = b.complete = b.launched = 0;
+  b.state.store(kFree, std::memory_order_release);
+  g->cv_free.notify_all();
+}
+
+void launcher_main(crn_ingest *g) {
+  (void)hipSetDevice(g->cfg.device);
+  std::deque<int> inflight;
+  std::vector<crn_epoch_result> res;
+  std::unique_lock<std::mutex> lk(g->mu);
+  for (;;) {
+    while (!g->work.empty()) {   // launch everything that is queued before waiting for anything
+      const int i = g->work.front();
+      g->work.pop_front();
+      lk.unlock();
+      const std::string err = enqueue(g, g->batch[i]);
+      lk.lock();
+      if (!err.empty()) {
+        if (g->err_code == CRN_OK) {
+          g->err_code = CRN_ERR_DEVICE;
+          g->err_msg = "ingest launch failed, batch dropped: " + err;
+        }
+        release_batch(g, g->batch[i]);
+      } else {
+        inflight.push_back(i);
+      }
+    }
+    if (inflight.empty()) {
+      if (g->stop) return;
+      g->cv_work.wait(lk);
+      continue;
+    }
+    Batch &b = g->batch[inflight.front()];
+    lk.unlock();
+    // one epoch is back within tens of microseconds: look a few times before sleeping
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 64 && q == hipErrorNotReady; spin++) q = hipEventQuery(b.done);
+    if (q == hipSuccess) {
+      res.clear();
+      collect(g, b, &res);
+      lk.lock();
+      for (const crn_epoch_result &r : res) g->ready.push_back(r);
+      release_batch(g, b);
+      inflight.pop_front();
+      continue;
+    }
+    lk.lock();
+    if (q != hipErrorNotReady) {
+      if (g->err_code == CRN_OK) {
+        g->err_code = CRN_ERR_DEVICE;
+        g->err_msg = std::string("ingest batch failed on the device: ") + hipGetErrorString(q);
+      }
+      release_batch(g, b);
+      inflight.pop_front();
+      continue;
+    }
+    if (g->work.empty()) g->cv_work.wait_for(lk, std::chrono::microseconds(20));  // new work wakes it early
+  }
+}
+
+// ---- caller's thread --------------------------------------------------------------------------
+
+bool is_free(const Batch &b) { return b.state.load(std::memory_order_acquire) == kFree; }
+
+int sticky_error(crn_ingest *g) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->err_code == CRN_OK) return CRN_OK;
+  const int code = g->err_code;
+  g->err_code = CRN_OK;
+  return crn::fail(code, g->err_msg);
+}
+
+// Hand the complete epochs of the batch being filled to the launcher thread (no HIP call, no wait).
+// Epochs that are still open move on to the other buffer — which must be free for that: CRN_ERR_BUSY
+// otherwise.
 int launch(crn_ingest *g) {
   Batch &b = g->batch[g->fill];
-  if (b.filled == 0) return CRN_OK;
-  const int n = b.filled;
-  HIP_TRY(hipMemcpyAsync(b.d_iq, b.h_iq, (size_t)n * g->epoch_floats * sizeof(float), hipMemcpyHostToDevice, g->stream));
-  crn_out o;
-  o.features = reinterpret_cast<float *>(b.d_res);
-  o.ann_out = reinterpret_cast<double *>(b.d_res + g->off_ann);
-  o.decision = reinterpret_cast<int32_t *>(b.d_res + g->off_dec);
-  o.occupancy = reinterpret_cast<uint8_t *>(b.d_res + g->off_occ);
-  o.spectrum = nullptr;
-  if (int rc = crn_sense_run_device(g->h, b.d_iq, n, g->L, 0, &o, g->stream)) return rc;
-  HIP_TRY(hipMemcpyAsync(b.h_res, b.d_res, g->res_bytes, hipMemcpyDeviceToHost, g->stream));
-  HIP_TRY(hipEventRecord(b.done, g->stream));
-  b.in_flight = true;
-  // switch to the other buffer; if it is still in flight, wait for it (back-pressure)
-  g->fill ^= 1;
-  Batch &nb = g->batch[g->fill];
-  if (nb.in_flight) {
-    HIP_TRY(hipEventSynchronize(nb.done));
-    harvest(g, nb);
+  if (b.complete == 0) return CRN_OK;
+  Batch &o = g->batch[g->fill ^ 1];
+  const bool holes = b.complete != b.assigned;
+  if (holes && !is_free(o)) return crn::fail(CRN_ERR_BUSY, "ingest ring: both batch buffers are in flight");
+  const int n = b.assigned;
+  b.launched = n;
+  b.L = g->L;
+  if (holes) {
+    // open epochs continue in the other buffer (their packets so far are copied over: this only
+    // happens when streams run at different rates or on an explicit flush)
+    for (int i = 0; i < n; i++) {
+      Slot &sl = b.slots[i];
+      if (sl.stream < 0 || sl.npk == g->K) continue;
+      const int j = o.assigned++;
+      o.slots[j] = sl;
+      std::memcpy(o.h_iq + (size_t)j * g->epoch_floats, b.h_iq + (size_t)i * g->epoch_floats,
+                  (size_t)sl.npk * g->L * 2 * sizeof(float));
+      g->open_slot[sl.stream] = j;
+      sl.stream = -1;
+    }
   }
+  b.state.store(kQueued, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->work.push_back(g->fill);
+  }
+  g->cv_work.notify_one();
+  g->fill ^= 1;
   return CRN_OK;
+}
+
+bool launch_due(const crn_ingest *g, const Batch &b) {
+  // once epochs_per_batch are complete — hole-free if possible (streams fed round-robin complete
+  // together), with holes only when the buffer has no slot left
+  return b.complete >= g->B && (b.complete == b.assigned || b.assigned == g->C);
+}
+
+void wait_free(crn_ingest *g, Batch &b) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->cv_free.wait(lk, [&] { return is_free(b); });
 }
 
 }  // namespace
@@ -130,23 +273,24 @@ int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_pack
   g->h = h;
   g->cfg = cfg;
   g->n_streams = n_streams;
-  g->L = samples_per_packet;
+  g->L = g->cap = samples_per_packet;
   g->B = epochs_per_batch;
+  // every stream can have one epoch open: with C >= n_streams a full buffer always holds a complete one
+  g->C = epochs_per_batch > n_streams ? epochs_per_batch : n_streams;
   g->K = cfg.frames_per_epoch;
   g->epoch_floats = (size_t)g->K * g->L * 2;
   const size_t nb = (size_t)cfg.n_bands;
-  g->off_ann = align_up((size_t)g->B * nb * sizeof(float), 256);
-  g->off_dec = g->off_ann + align_up((size_t)g->B * 3 * sizeof(double), 256);
-  g->off_occ = g->off_dec + align_up((size_t)g->B * sizeof(int32_t), 256);
-  g->res_bytes = g->off_occ + align_up((size_t)g->B * nb, 256);
-  g->staging.assign(n_streams, std::vector<float>(g->epoch_floats, 0.f));
-  g->packets.assign(n_streams, 0);
+  g->off_ann = align_up((size_t)g->C * nb * sizeof(float), 256);
+  g->off_dec = g->off_ann + align_up((size_t)g->C * 3 * sizeof(double), 256);
+  g->off_occ = g->off_dec + align_up((size_t)g->C * sizeof(int32_t), 256);
+  g->res_bytes = g->off_occ + align_up((size_t)g->C * nb, 256);
+  g->open_slot.assign(n_streams, -1);
   g->seq.assign(n_streams, 0);
   hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     Batch &b = g->batch[i];
-    b.tags.resize(g->B);
-    const size_t iq_bytes = (size_t)g->B * g->epoch_floats * sizeof(float);
+    b.slots.resize(g->C);
+    const size_t iq_bytes = (size_t)g->C * g->epoch_floats * sizeof(float);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_iq), iq_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.d_iq), iq_bytes);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_res), g->res_bytes, hipHostMallocDefault);
@@ -157,44 +301,100 @@ int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_pack
     crn_ingest_destroy(g);
     return crn::fail(CRN_ERR_NOMEM, std::string("crn_ingest_create: ") + hipGetErrorString(e));
   }
+  g->launcher = std::thread(launcher_main, g);
   *out = g;
+  return CRN_OK;
+}
+
+int crn_ingest_set_packet_len(crn_ingest *g, int32_t samples_per_packet) {
+  if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
+  if (samples_per_packet < 1 || samples_per_packet > g->cap)
+    return crn::fail(CRN_ERR_ARG, "samples_per_packet must be in 1..the length the ring was created with");
+  if (samples_per_packet == g->L) return CRN_OK;
+  Batch &b = g->batch[g->fill];
+  if (!is_free(b)) return crn::fail(CRN_ERR_BUSY, "ingest ring: both batch buffers are in flight");
+  if (b.assigned != 0) return crn::fail(CRN_ERR_STATE, "crn_ingest_set_packet_len: epochs are staged (flush first)");
+  g->L = samples_per_packet;
+  g->epoch_floats = (size_t)g->K * g->L * 2;
   return CRN_OK;
 }
 
 int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) {
   if (!g || !iq_packet) return crn::fail(CRN_ERR_ARG, "crn_ingest_push: null argument");
   if (stream < 0 || stream >= g->n_streams) return crn::fail(CRN_ERR_ARG, "stream id out of range");
-  std::vector<float> &st = g->staging[stream];
-  std::memcpy(st.data() + (size_t)g->packets[stream] * g->L * 2, iq_packet, (size_t)g->L * 2 * sizeof(float));
-  if (++g->packets[stream] < g->K) return CRN_OK;
-  // epoch complete: pack it into the batch being filled
-  g->packets[stream] = 0;
-  Batch &b = g->batch[g->fill];
-  std::memcpy(b.h_iq + (size_t)b.filled * g->epoch_floats, st.data(), g->epoch_floats * sizeof(float));
-  b.tags[b.filled] = SlotTag{stream, g->seq[stream]++};
-  if (++b.filled == g->B) return launch(g);
-  return CRN_OK;
+  for (int attempt = 0;; attempt++) {
+    Batch &b = g->batch[g->fill];
+    if (!is_free(b)) {
+      g->dropped++;
+      return crn::fail(CRN_ERR_BUSY, "ingest ring: both batch buffers are in flight, packet refused");
+    }
+    int sl = g->open_slot[stream];
+    if (sl < 0) {
+      if (b.assigned == g->C) {  // no free slot: send the complete epochs off, carry the open ones over
+        if (attempt > 0) return crn::fail(CRN_ERR_STATE, "ingest ring: no slot after a launch");
+        if (int rc = launch(g)) {
+          if (rc == CRN_ERR_BUSY) g->dropped++;
+          return rc;
+        }
+        continue;  // the fill buffer changed
+      }
+      sl = b.assigned++;
+      b.slots[sl] = Slot{stream, g->seq[stream]++, 0};
+      g->open_slot[stream] = sl;
+    }
+    Slot &s = b.slots[sl];
+    std::memcpy(b.h_iq + (size_t)sl * g->epoch_floats + (size_t)s.npk * g->L * 2, iq_packet,
+                (size_t)g->L * 2 * sizeof(float));
+    if (++s.npk < g->K) return CRN_OK;
+    g->open_slot[stream] = -1;
+    b.complete++;
+    if (launch_due(g, b)) {
+      const int rc = launch(g);
+      return rc == CRN_ERR_BUSY ? CRN_OK : rc;  // this packet is staged; the hand-off is retried by the next push / poll
+    }
+    return CRN_OK;
+  }
 }
 
 int crn_ingest_flush(crn_ingest *g) {
   if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
-  return launch(g);
+  if (!is_free(g->batch[g->fill])) return CRN_OK;  // nothing can be staged in a buffer that is on the GPU
+  int rc = launch(g);
+  if (rc == CRN_ERR_BUSY) {  // open epochs need the other buffer: wait for it (flush may block, push never does)
+    wait_free(g, g->batch[g->fill ^ 1]);
+    rc = launch(g);
+  }
+  return rc;
+}
+
+int crn_ingest_wait(crn_ingest *g) {
+  if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
+  wait_free(g, g->batch[g->fill]);
+  return sticky_error(g);
 }
 
 int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, int32_t *n_out) {
   if (!g || !n_out || (max_results > 0 && !out)) return crn::fail(CRN_ERR_ARG, "crn_ingest_poll: null argument");
-  // the batch launched before the current fill buffer's twin is the older one
-  for (int k = 0; k < 2; k++) {
-    Batch &b = g->batch[g->fill ^ 1 ^ k];
-    if (!b.in_flight) continue;
-    hipError_t q = hipEventQuery(b.done);
-    if (q == hipSuccess) harvest(g, b);
-    else if (q != hipErrorNotReady) return crn::fail(CRN_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  *n_out = 0;
+  {  // a hand-off that found both buffers busy is retried here as well as by the next push
+    Batch &b = g->batch[g->fill];
+    if (is_free(b) && launch_due(g, b)) {
+      const int rc = launch(g);
+      if (rc != CRN_OK && rc != CRN_ERR_BUSY) return rc;
+    }
   }
   int n = 0;
-  while (n < max_results && !g->ready.empty()) {
-    out[n++] = g->ready.front();
-    g->ready.pop_front();
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->err_code != CRN_OK) {
+      const int code = g->err_code;
+      g->err_code = CRN_OK;
+      return crn::fail(code, g->err_msg);
+    }
+    while (n < max_results && !g->ready.empty()) {
+      out[n++] = g->ready.front();
+      g->ready.pop_front();
+    }
   }
   *n_out = n;
   return CRN_OK;
@@ -202,18 +402,29 @@ int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, i
 
 int crn_ingest_drain(crn_ingest *g) {
   if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
-  if (int rc = launch(g)) return rc;
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  // harvest in launch order: the buffer that is NOT the fill buffer was launched last
-  Batch &older = g->batch[g->fill];
-  Batch &newer = g->batch[g->fill ^ 1];
-  if (older.in_flight) harvest(g, older);
-  if (newer.in_flight) harvest(g, newer);
+  if (int rc = crn_ingest_flush(g)) return rc;
+  wait_free(g, g->batch[0]);
+  wait_free(g, g->batch[1]);
+  return sticky_error(g);
+}
+
+int crn_ingest_dropped(crn_ingest *g, int64_t *n_packets) {
+  if (!g || !n_packets) return crn::fail(CRN_ERR_ARG, "null argument");
+  *n_packets = g->dropped;
   return CRN_OK;
 }
 
 int crn_ingest_destroy(crn_ingest *g) {
   if (!g) return CRN_OK;
+  if (g->launcher.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->stop = true;
+    }
+    g->cv_work.notify_all();
+    g->launcher.join();  // launches what is queued, waits for what is in flight
+  }
+  (void)hipSetDevice(g->cfg.device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   for (int i = 0; i < 2; i++) {
     Batch &b = g->batch[i];

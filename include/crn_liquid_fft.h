@@ -8,9 +8,15 @@
  * (liquid.h of git a4d7c80d3: liquid_float_complex = float _Complex in C / std::complex<float> in
  * C++; fftplan is an opaque pointer; LIQUID_FFT_FORWARD = +1, LIQUID_FFT_BACKWARD = -1).
  *
- * Scope: forward transforms of N in {512, 1024, 2048, 4096} (the sizes of the sensing kernel).
- * Anything else follows the reference's error convention for set-up failures — a message on stderr
- * and exit(EXIT_FAILURE) (src/crts.cpp:111-115) — because the liquid API has no error return.
+ * Scope: forward transforms of N in {512, 1024, 2048, 4096} (the sizes of the sensing kernel) run on
+ * the GPU.  Any other (n, dir) — liquid's own internal plans included: the ECR constructor's
+ * ofdmflexframegen_create / ofdmflexframesync_create (src/extensible_cognitive_radio.cpp:113,123) build
+ * backward plans of the subcarrier count through these same symbols once this library precedes
+ * -lliquid — is handed to the next definition in the search order (dlsym(RTLD_NEXT, ..): liquid's), and
+ * fft_execute / fft_destroy_plan dispatch on which library created the plan.  Only when there is no next
+ * definition, or no GPU for a sensing plan, does the reference's error convention for set-up failures apply —
+ * a message on stderr and exit(EXIT_FAILURE) (src/crts.cpp:111-115) — because the liquid API has no error
+ * return.  There is no CPU fallback for the sensing sizes.
  *
  * One fft_execute is one host->device copy, one launch and one device->host copy: it is the drop-in
  * for an engine that must link unchanged, not the fast path (that is crn_sense_run_device, which
@@ -40,6 +46,8 @@ __attribute__((visibility("default"))) fftplan fft_create_plan(unsigned int n, l
                                                                liquid_float_complex *y, int dir, int flags);
 __attribute__((visibility("default"))) void fft_execute(fftplan p);
 __attribute__((visibility("default"))) void fft_destroy_plan(fftplan p);
+/* diagnostic: plans handed on to the next definition (liquid's) so far */
+__attribute__((visibility("default"))) long crn_liquid_fft_forwarded(void);
 
 #ifdef __cplusplus
 }

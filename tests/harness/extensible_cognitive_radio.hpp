@@ -1,4 +1,5 @@
-// extensible_cognitive_radio.hpp — the slice of the ECR that a sensing engine touches.
+// extensible_cognitive_radio.hpp — TEST DOUBLE: the slice of the ECR that a sensing engine touches.
+// (Lives under tests/: in a CRTS tree the engine compiles against the real header.)
 //
 // The reference's ExtensibleCognitiveRadio (include/extensible_cognitive_radio.hpp, 1000+ lines)
 // owns two UHD USRP handles, the liquid-dsp OFDM PHY, a TUN device and three pthreads; none of
@@ -18,6 +19,8 @@
 // reference's (CE_Predictive_Node.cpp:66-69,133-134,159,247,252,257).
 #ifndef _ECR_HARNESS_HPP_
 #define _ECR_HARNESS_HPP_
+
+#include <time.h>
 
 #include <complex>
 #include <string>
@@ -43,10 +46,17 @@ public:
   struct Call {
     std::string name;
     double arg;
+    double t;  // seconds since the double was constructed
   };
 
   ExtensibleCognitiveRadio() : ce_usrp_rx_buffer(nullptr), ce_usrp_rx_buffer_length(0), CE(nullptr), ce_sensing_flag(0) {
     CE_metrics.CE_event = TIMEOUT;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+  }
+  double now() const {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
   }
 
   struct metric_s CE_metrics;
@@ -55,17 +65,18 @@ public:
 
   void set_ce_sensing(int ce_sensing) {
     ce_sensing_flag = ce_sensing;
-    calls.push_back(Call{"set_ce_sensing", (double)ce_sensing});
+    calls.push_back(Call{"set_ce_sensing", (double)ce_sensing, now()});
   }
-  void set_tx_freq(double f) { calls.push_back(Call{"set_tx_freq", f}); }
-  void stop_tx() { calls.push_back(Call{"stop_tx", 0.0}); }
-  void set_rx_freq(double f) { calls.push_back(Call{"set_rx_freq", f}); }
-  void set_rx_rate(double r) { calls.push_back(Call{"set_rx_rate", r}); }
+  void set_tx_freq(double f) { calls.push_back(Call{"set_tx_freq", f, now()}); }
+  void stop_tx() { calls.push_back(Call{"stop_tx", 0.0, now()}); }
+  void set_rx_freq(double f) { calls.push_back(Call{"set_rx_freq", f, now()}); }
+  void set_rx_rate(double r) { calls.push_back(Call{"set_rx_rate", r, now()}); }
 
   // harness side
   CognitiveEngine *CE;
   int ce_sensing_flag;
   std::vector<Call> calls;
+  struct timespec t0;
 };
 
 #endif

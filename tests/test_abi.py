@@ -21,9 +21,18 @@ def test_header_symbols_are_exported(built):
     assert L.crn_abi_version() == cs.CRN_ABI_VERSION
 
 
+def test_engine_directory_is_self_contained(built):
+    """a CRTS tree copies cognitive_engines/CE_Predictive_Node_GPU/ as it is, so the directory
+    carries CE_X.cpp + CE_X.hpp (what src/config_cognitive_engines.cpp:43-61 requires) and its own, identical,
+    copy of the C ABI header — and no test double."""
+    d = os.path.join(ROOT, "cognitive-radio-network_amd", "cognitive_engines", "CE_Predictive_Node_GPU")
+    assert sorted(os.listdir(d)) == ["CE_Predictive_Node_GPU.cpp", "CE_Predictive_Node_GPU.hpp", "crn_sense.h"]
+    assert open(os.path.join(d, "crn_sense.h")).read() == open(os.path.join(ROOT, "include", "crn_sense.h")).read()
+
+
 def test_cfg_struct_layout_round_trips(built):
     c = cs.cfg_energy_scaled(4096, 4.0)
-    assert (c.abi_version, c.fft_len, c.frames_per_epoch, c.hop) == (1, 4096, 10, 4096)
+    assert (c.abi_version, c.fft_len, c.frames_per_epoch, c.hop) == (cs.CRN_ABI_VERSION, 4096, 10, 4096)
     assert (c.mode, c.decide, c.window, c.n_bands, c.n_segs, c.ref_band) == (1, 1, 0, 4, 5, 0)
     segs = [(c.segs[i].lo, c.segs[i].hi, c.segs[i].band) for i in range(5)]
     assert segs == [(0, 128, 1), (3968, 4088, 1), (440, 680, 2), (1512, 1776, 3), (2400, 2480, 0)]
