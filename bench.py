@@ -13,19 +13,29 @@ Default workload = the configuration the metric is quoted on (SURVEY.md §8d "cf
 
 Multi-GPU: the path shards by stream — every rank owns its own epochs (weak
 scaling, per-GPU work fixed) and the only exchange is an RCCL all-gather of the per-epoch
-occupancy vector after each step.
+occupancy vector after each step, made through the C ABI (crn_comm_*: side stream, two slots, so it
+overlaps the next launch).  torch.distributed (gloo) is the control plane only: the RCCL unique id,
+the barriers around the timed region and the max over ranks.
 
 Warm-up: W untimed steps, topped up to ~50 ms of launches when W is small (clock ramp), then
-exactly K timed steps between barrier + synchronize pairs.
+exactly K timed steps between barrier + synchronize pairs, every launch bracketed by its own event
+pair on the launch stream.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     HBM-bound: algorithmic bytes (8 B per input sample) / mean kernel time, measured with
-               events on the launch stream, against the 8 TB/s peak
-  cpu_baseline the oracle (CPU restatement of the reference path) timed on this box's host cores
-               on a bounded sample of the same data (rank 0, N = 1 only)
+  roofline      HBM-bound: algorithmic bytes (8 B per unique input sample) / mean kernel time from the
+                per-launch events, against the 8 TB/s peak; min / median / max per launch alongside
+  roofline_valu (windowed / Welch modes, which are VALU-issue-bound) algorithmic flops against the fp32
+                vector peak, plus the measured VALU-busy fraction at the measured clock from the committed
+                counter passes of the same command (profiles/r02_valu_counters.json)
+  config.alt    (N = 1, headline workload) the same kernel on SURVEY.md §8(d)'s 2 GiB batch, and the
+                kernel any other band table / a spectrum request gets (no row pruning)
+  cpu_baseline  the oracle (CPU restatement of the reference path, built -O2 -march=native on this box)
+                timed on this box's host cores on a bounded sample of the same data: all cores (`value`)
+                and one thread — the reference's own topology — median of 3 passes of >= 3 s each
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -34,7 +44,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cognitive-radio-network_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_VECTOR_PEAK_TF = 157.3  # same guide: peak FP32 (vector), spec, at 2.4 GHz
+
+
+def usable_cores():
+    """CPU threads this process can really run at once: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes expose 256 hardware threads under a 16-CPU quota: 256 OpenMP threads there run 5x SLOWER
+    than 16, tools/cpu_scaling.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = f"{n} threads = affinity mask"
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                q = max(1, int(math.ceil(int(quota) / int(period))))
+                if q < n:
+                    n, why = q, f"{q} threads = cgroup CPU quota ({quota.strip()}/{period.strip()})"
+        except Exception:
+            pass
+    try:  # cgroup v1
+        q, p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and int(math.ceil(q / p)) < n:
+            n, why = int(math.ceil(q / p)), f"{int(math.ceil(q / p))} threads = cgroup CPU quota ({q}/{p})"
+    except Exception:
+        pass
+    return n, why
 
 
 def main():
@@ -48,12 +83,15 @@ def main():
                     help="scan = cfg4's wideband scan: the welch kernel, streams of 64 channels sharded over the ranks")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
     ap.add_argument("--frames", type=int, default=0, help="frames per epoch K (0 = the configuration's own, 10)")
-    ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip)")
-    ap.add_argument("--per-launch-events", action="store_true", help="time each launch with its own event pair")
+    ap.add_argument("--cpu-epochs", type=int, default=-1, help="oracle sample size (-1 = auto, 0 = skip the CPU baseline)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the config.alt legs (2 GiB batch, unpruned kernel)")
+    ap.add_argument("--span-events", action="store_true",
+                    help="one event pair around all timed launches instead of one pair per launch")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
     ap.add_argument("--force-collective", action="store_true",
                     help="dry run of the N>1 code path on one GPU: RCCL group of one rank, all-gather every step")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
+    ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "r02_valu_counters.json"))
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: everything else this process (or a library under it:
@@ -66,7 +104,7 @@ def main():
     import torch.distributed as dist
 
     import crnsense as cs
-    from sharding import OccupancyExchange, shard
+    from sharding import DeviceOccupancyExchange, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -78,29 +116,31 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_collective
-    if multi:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")   # control plane only; the data-path collective is crn_comm_* (RCCL)
 
     if args.mode == "ref":
         cfg = cs.cfg_reference()
         workload = "cfg3: 512-pt |X| mean x10 + 4-5-3 ANN cascade (reference-exact)"
+        label = "512-pt x 3ch reference-exact + ANN"
     elif args.mode in ("welch", "scan"):
         cfg = cs.cfg_welch(args.fft, 8, 64)
         for b in range(64):
             cfg.thresh[b] = 1e-2
         workload = f"cfg2: {args.fft}-pt Welch PSD (Hann, 50% overlap) x 64 bands + threshold"
+        label = f"{args.fft}-pt Welch x 64ch"
         if args.mode == "scan":
             # BASELINE.json configs[4]: 256 channels = 4 streams x 64 bands is the shard unit; a rank's batch
             # is thousands of such units (one epoch of one stream each), the occupancy gather is [epochs, 64]
             workload = (f"cfg4: wideband scan, {args.fft}-pt Welch x 64 channels per stream (256 channels = 4 streams), "
                         "streams sharded over the ranks, occupancy all-gather")
+            label = f"{args.fft}-pt Welch scan x 64ch per stream"
     else:
         cfg = cs.cfg_energy_scaled(args.fft, 4.0)
         workload = f"{args.fft}-pt FFT + energy detect x 3ch (+noise-floor band), K=10, threshold"
+        label = f"{args.fft}-pt x 3ch"
     cfg.device = local_rank
     if args.frames > 0:
         cfg.frames_per_epoch = args.frames
@@ -115,6 +155,9 @@ def main():
     sensor = cs.Sensor(cfg)
     sensor.set_variant(args.variant)
     info = sensor.kernel_info()
+    pruned = "PASS3_ROWS" in info["name"]
+    if pruned:
+        workload += " [kernel specialised to the reference channel plan's 7 of 16 output rows; config.alt.unpruned = any other plan]"
 
     iq = torch.zeros(n_samples * 2, dtype=torch.float32, device=dev)
     truth = torch.empty(E, dtype=torch.int32, device=dev)
@@ -127,149 +170,233 @@ def main():
                              stream=stream)
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
-    # N > 1: the occupancy block alternates between two slots so that the all-gather of step i
-    # (side stream) overlaps the sensing kernel of step i + 1 (sharding.OccupancyExchange)
-    ex = OccupancyExchange(E, cfg.n_bands, dev) if multi else None
+    # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the
+    # all-gather of step i (side stream) overlaps the sensing kernel of step i + 1
+    ex = DeviceOccupancyExchange(E, cfg.n_bands, local_rank, rank, world) if multi else None
     n_done = 0
 
-    def step():
+    def step(sn, epochs, out_ptrs, ev=None):
         nonlocal n_done
-        if multi:
-            outs["occupancy"] = ex.local(n_done).data_ptr()
-        sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
-        if multi:
-            ex.exchange(n_done)
+        if ex is not None:
+            out_ptrs["occupancy"] = ex.local_ptr(n_done, stream)
+        if ev is not None:
+            ev[0].record()
+        sn.run_device(iq.data_ptr(), epochs, N, out_ptrs, stream=stream)
+        if ev is not None:
+            ev[1].record()
+        if ex is not None:
+            ex.exchange(n_done, stream)
         n_done += 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     # Clock ramp: on this part a cold process needs ~25 ms of back-to-back launches before the
     # per-launch time settles, so the W warm-up steps are topped up to at least
     # ~50 ms of untimed work when W is small.  The timed region below is exactly K steps.
     prewarm = max(args.warmup, int(0.05 / 1.6e-3 * (28672 * 40960) / max(E * spe, 1)) + 1)
     for _ in range(prewarm):
-        step()
+        step(sensor, E, outs)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     span[0].record()
     for i in range(args.steps):
-        if multi:
-            outs["occupancy"] = ex.local(n_done).data_ptr()
-        if multi or args.per_launch_events:
-            ev[i][0].record()
-        sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
-        if multi or args.per_launch_events:
-            ev[i][1].record()
-        if multi:
-            ex.exchange(n_done)
-        n_done += 1
-    if multi:
-        ex.finish()
-        occ = ex.local_bufs[(n_done - 1) % ex.depth]
+        step(sensor, E, outs, None if args.span_events else ev[i])
+    if ex is not None:
+        ex.finish(stream)
     span[1].record()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # Kernel duration from events on the launch stream.  One GPU: one pair around the K back-to-back
-    # launches (mean includes the ~us dispatch gap between consecutive kernels, no per-event cost).
-    # Several GPUs: a pair per launch, because the all-gather sits between launches.
-    if multi or args.per_launch_events:
-        kern_ms = [a.elapsed_time(b) for a, b in ev]
-    else:
+    # Kernel duration from events on the launch stream: one pair per launch (default), so min / median /
+    # max are real per-launch figures; --span-events: one pair around the K back-to-back launches.
+    if args.span_events:
         kern_ms = [span[0].elapsed_time(span[1]) / args.steps]
+    else:
+        kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_ms_mean = float(np.mean(kern_ms))
     samples_per_step = E * spe * world
     value = samples_per_step * args.steps / dt / 1e6  # Msamples/s, whole job
     algo_bytes = E * spe * 8                          # per launch: 8 B per unique input sample
     achieved = algo_bytes / (kern_ms_mean * 1e-3) / 1e9
 
-    # sanity on the timed outputs: decisions must follow the driven occupancy pattern
+    # ---- sanity on the timed outputs ----------------------------------------------------------------
+    last = n_done - 1
+    occ_host = ex.local_host(last) if ex is not None else occ.cpu().numpy()
     picked = truth.cpu().numpy()
     if args.no_check:
         pass
     elif cfg.decide == cs.DECIDE_THRESHOLD and cfg.ref_band >= 0:
-        o = occ.cpu().numpy()
-        want = np.zeros_like(o)
+        want = np.zeros_like(occ_host)
         idx = np.nonzero(picked > 0)[0]
         want[idx, picked[idx]] = 1
-        mism = int((o != want).any(axis=1).sum())
+        mism = int((occ_host != want).any(axis=1).sum())
         if mism:
             raise SystemExit(f"bench: {mism} epochs whose occupancy differs from the driven pattern")
     elif cfg.decide == cs.DECIDE_ANN:
         mism = int((dec.cpu().numpy() != picked).sum())
         if mism:
             raise SystemExit(f"bench: {mism} epochs whose decision differs from the driven pattern")
+    if not args.no_check and rank == 0:
+        # every mode, even with --cpu-epochs 0: a small sample of the timed launch's outputs against the oracle
+        import oracle_py as orc
+        n_chk = min(E, 16)
+        host_iq = iq[: cs.samples_needed(cfg, n_chk) * 2].cpu().numpy()
+        ref = orc.run(cfg, host_iq, n_chk)
+        g = feats[:n_chk].cpu().numpy()
+        rel = np.abs(g - ref["features"]) / np.maximum(np.abs(ref["features"]), 1e-30)
+        if rel.max() > 1e-5 or not np.array_equal(occ_host[:n_chk], ref["occupancy"]):
+            raise SystemExit(f"bench: GPU results differ from the oracle on the first {n_chk} epochs (rel {rel.max():.3g})")
+    if ex is not None and not args.no_check:
+        # every rank must find its own block, unchanged, at its place in the gathered vector
+        torch.cuda.synchronize()
+        if not np.array_equal(ex.gathered_host(last)[rank * E:(rank + 1) * E], occ_host):
+            raise SystemExit(f"bench: rank {rank}: gathered occupancy differs from the local block")
 
-    traffic = None
-    if os.path.exists(args.traffic_json):
+    def committed(path, key):
+        if not os.path.exists(path):
+            return None
         try:
-            tj = json.load(open(args.traffic_json))
-            key = f"{'welch' if args.mode == 'scan' else args.mode}{N}"
-            if key in tj:  # measured once per kernel; scales linearly with the batch
-                traffic = int(tj[key]["hbm_bytes_per_launch"] * (E / tj[key]["epochs"]))
+            return json.load(open(path)).get(key)
         except Exception:
-            traffic = None
+            return None
 
+    mode_key = f"{'welch' if args.mode == 'scan' else args.mode}{N}"
+    traffic = None
+    tj = committed(args.traffic_json, mode_key)
+    if tj:  # measured once per kernel with rocprofv3 PMC passes of this command; scales linearly with the batch
+        traffic = int(tj["hbm_bytes_per_launch"] * (E / tj["epochs"]))
+
+    # ---- second roofline for the windowed kernels: VALU ---------------------------------------------
+    roofline_valu = None
+    if cfg.window != cs.WINDOW_RECT or args.mode in ("welch", "scan"):
+        frames = E * K
+        # algorithmic flops per N-point frame: FFT 5 N log2 N, window 2 N, |X|^2 accumulate 4 N
+        flops = frames * (5.0 * N * math.log2(N) + 2.0 * N + 4.0 * N)
+        tf = flops / (kern_ms_mean * 1e-3) / 1e12
+        roofline_valu = {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / FP32_VECTOR_PEAK_TF,
+                         "note": "algorithmic flops (5 N log2 N + 6 N per frame; every hop of N/2 new samples costs a whole "
+                                 "N-point transform) against the fp32 vector peak at 2.4 GHz; butterflies are add-heavy, "
+                                 "so issue slots, not flops, are what runs out: see issue_frac"}
+        vj = committed(args.valu_json, mode_key)
+        if vj:
+            roofline_valu.update({"issue_frac": vj["valu_busy_frac"], "clock_ghz": vj["clock_ghz"],
+                                  "valu_insts_per_wave_frame": vj["valu_insts_per_wave_frame"],
+                                  "issue_frac_source": vj["source"]})
+
+    # ---- config.alt: the same metric on SURVEY.md §8(d)'s 2 GiB batch, and without row pruning -------
+    alt = None
+    if rank == 0 and world == 1 and not multi and not args.no_alt and args.mode == "energy" and args.variant == 0 \
+            and args.epochs == 0 and args.frames == 0:
+        def leg(sn, epochs, n=50):
+            for _ in range(max(20, int(0.03 / 1.6e-3 * E / epochs))):
+                sn.run_device(iq.data_ptr(), epochs, N, outs, stream=stream)
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in pairs:
+                a.record()
+                sn.run_device(iq.data_ptr(), epochs, N, outs, stream=stream)
+                b.record()
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            gbs = epochs * spe * 8 / (float(np.mean(ms)) * 1e-3) / 1e9
+            return {"epochs": epochs, "bytes_per_step": epochs * spe * 8, "kernel_ms_mean": float(np.mean(ms)),
+                    "kernel_ms_median": float(np.median(ms)), "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+                    "Msamples/s": epochs * spe / (float(np.mean(ms)) * 1e-3) / 1e6}
+        e2g = (2 ** 28) // spe   # SURVEY.md §8(d) cfgH: B = 2^28 / 4096 = 65 536 frames = 2 GiB
+        alt = {"cfgH_2GiB_batch": dict(leg(sensor, e2g), kernel=info["name"][:40] + "...",
+                                       note="SURVEY.md §8(d) cfgH batch: 2^28 samples per launch (launch ramp and tail weigh more)")}
+        s2 = cs.Sensor(cfg)
+        s2.set_variant(2)
+        alt["unpruned"] = dict(leg(s2, E), kernel=s2.kernel_info()["name"],
+                               note="what any band table outside the reference plan's rows, or a spectrum request, runs")
+        s2.close()
+
+    # ---- CPU baseline ---------------------------------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_epochs != 0:
         import oracle_py as orc
-        cores = os.cpu_count() or 1
+        native = orc.use_native_build()       # -O2 -march=native, compiled on this box (the portable build otherwise)
+        hw = os.cpu_count() or 1
+        cores, why = usable_cores()          # threads actually used: the container's CPU quota, not the host's thread count
         cap = max(1, (7168 * 40960) // spe)   # at most 2.2 GiB of the batch goes to the host
-        n_cpu = args.cpu_epochs if args.cpu_epochs > 0 else min(E, cap, 64 * cores)
-        host_iq = iq[: cs.samples_needed(cfg, n_cpu) * 2].cpu().numpy()
-        orc.run(cfg, host_iq, min(n_cpu, 2 * cores), n_threads=cores)  # warm-up (page in, plan)
-        t1 = time.perf_counter()
-        ref = orc.run(cfg, host_iq, n_cpu, n_threads=cores)
-        t_cpu = time.perf_counter() - t1
-        if args.cpu_epochs < 0 and t_cpu < 5.0:  # grow the sample to ~10 s of CPU work
-            n_cpu = int(min(E, cap, n_cpu * 10.0 / max(t_cpu, 1e-3)))
-            host_iq = iq[: cs.samples_needed(cfg, n_cpu) * 2].cpu().numpy()
+        n_all = args.cpu_epochs if args.cpu_epochs > 0 else min(E, cap)
+        host_iq = iq[: cs.samples_needed(cfg, n_all) * 2].cpu().numpy()
+        quick = args.cpu_epochs > 0           # explicit sample size: one pass each (tests)
+
+        def timed(n_ep, threads, min_s):
+            orc.run(cfg, host_iq, min(n_ep, 2 * threads), n_threads=threads)  # warm-up (page in, plan)
             t1 = time.perf_counter()
-            ref = orc.run(cfg, host_iq, n_cpu, n_threads=cores)
-            t_cpu = time.perf_counter() - t1
+            orc.run(cfg, host_iq, n_ep, n_threads=threads)
+            one = time.perf_counter() - t1
+            reps = 1 if quick else max(1, int(math.ceil(min_s / max(one, 1e-3))))
+            rates = []
+            for _ in range(1 if quick else 3):
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    ref_out = orc.run(cfg, host_iq, n_ep, n_threads=threads)
+                rates.append(n_ep * spe * reps / (time.perf_counter() - t1) / 1e6)
+            return float(np.median(rates)), rates, reps, ref_out
+
+        all_rate, all_rates, all_reps, ref = timed(n_all, cores, 3.0)
+        n_one = n_all if quick else max(1, n_all // 4)   # ~0.6 s of one thread per repetition
+        one_rate, one_rates, one_reps, _ = timed(n_one, 1, 3.0)
         # the same sample doubles as a parity check of the timed GPU outputs
-        g = feats[:n_cpu].cpu().numpy()
+        g = feats[:n_all].cpu().numpy()
         rel = np.abs(g - ref["features"]) / np.maximum(np.abs(ref["features"]), 1e-30)
-        if rel.max() > 1e-5 or not np.array_equal(occ[:n_cpu].cpu().numpy(), ref["occupancy"]):
+        if not args.no_check and (rel.max() > 1e-5 or not np.array_equal(occ_host[:n_all], ref["occupancy"])):
             raise SystemExit(f"bench: GPU results differ from the oracle on the CPU sample (rel {rel.max():.3g})")
-        cpu = {"value": n_cpu * spe / t_cpu / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_cpu} epochs ({n_cpu * spe * 8 / 2**20:.0f} MiB) of the GPU batch, "
-                         f"oracle/crn_oracle.c (liquid-dsp-style fp32 radix-2 restated) on {cores} threads, "
-                         f"{t_cpu:.1f} s"}
+        build = "gcc -O2 -march=native -ffp-contract=off, built on this box" if native else "gcc -O2 -ffp-contract=off (portable build)"
+        cpu = {"value": all_rate, "unit": "Msamples/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_all} epochs ({n_all * spe * 8 / 2**20:.0f} MiB) of the GPU batch x {all_reps} per pass, "
+                         f"oracle/crn_oracle.c (liquid-dsp-style fp32 radix-2 restated; {build}) on {cores} threads, "
+                         f"median of {len(all_rates)} passes; {why} (host: {hw} hardware threads)",
+               "passes": all_rates,
+               "one_thread": {"value": one_rate, "unit": "Msamples/s", "cores": 1,
+                              "sample": f"first {n_one} epochs x {one_reps} per pass, median of {len(one_rates)} passes: the "
+                                        "reference's own topology (one CE pthread, src/extensible_cognitive_radio.cpp:1761-1808)",
+                              "passes": one_rates}}
 
     if rank == 0:
         if os.environ.get("CRN_BENCH_DUMP"):
             print("kernel_ms per step:", " ".join(f"{x:.3f}" for x in kern_ms), file=sys.stderr)
         line = {
-            "metric": "Msamples/s IQ through FFT+energy-detect, 4096-pt x 3ch; % HBM roofline",
+            "metric": f"Msamples/s IQ through FFT+energy-detect, {label}; % HBM roofline",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
                        "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
-                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy" if multi else "")},
+                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy (crn_comm_*, side stream)" if multi else ""),
+                       "alt": alt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of "
+                                            "this command, scaled by the batch") if traffic else None,
                          "kernel_ms_mean": kern_ms_mean, "kernel_ms_min": float(np.min(kern_ms)),
-                         "kernel_ms_median": float(np.median(kern_ms))},
+                         "kernel_ms_median": float(np.median(kern_ms)), "kernel_ms_max": float(np.max(kern_ms)),
+                         "events": "span" if args.span_events else "per-launch"},
             "cpu_baseline": cpu,
         }
+        if roofline_valu is not None:
+            line["roofline_valu"] = roofline_valu
+            line["roofline"]["note"] = "this mode is VALU-issue-bound, not HBM-bound: see roofline_valu"
         print(json.dumps(line), file=json_out, flush=True)
-    if multi:
-        # every rank must find its own block, unchanged, at its place in the gathered vector
-        if not args.no_check and not torch.equal(ex.gathered(n_done - 1)[rank * E:(rank + 1) * E], occ):
-            raise SystemExit(f"bench: rank {rank}: gathered occupancy differs from the local block")
+    if ex is not None:
+        torch.cuda.synchronize()
+        ex.close()
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

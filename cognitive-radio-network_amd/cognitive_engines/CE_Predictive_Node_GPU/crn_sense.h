@@ -244,6 +244,43 @@ CRN_API int crn_ingest_drain(crn_ingest *g);
 CRN_API int crn_ingest_dropped(crn_ingest *g, int64_t *n_packets);
 CRN_API int crn_ingest_destroy(crn_ingest *g);
 
+/* -- multi-GPU: the occupancy exchange ----------------------------------------------------------
+ * The path shards by stream: every (stream, epoch) is independent — the only state that crosses
+ * frames is the K-frame mean inside one epoch of one stream (fft_avg[], CE_Predictive_Node.hpp:51) —
+ * so each GPU (one process per GPU, one crn_handle each) runs crn_sense_run_device on its own
+ * streams' batch with no data-path collective.  The one exchange: every node's engine needs the whole
+ * occupancy picture to pick a free channel, so each rank contributes its [epochs][n_bands] uint8
+ * block to an all-gather over RCCL (xGMI inside a node).  Latency-bound (KiB per rank): one
+ * collective per batch, queued on a side stream behind an event so that it overlaps the next launch;
+ * `depth` slots so that step i + 1's kernel can write while step i's gather is in flight.
+ *
+ *   rank 0: crn_comm_unique_id(id), handed to the other ranks out of band (any launcher's store)
+ *   all:    crn_comm_create(device, rank, world, id, epochs * n_bands, 2, &c)        (collective)
+ *   step i: crn_comm_local(c, i, stream, &occ)   -> crn_out.occupancy = occ; crn_sense_run_device(.., stream)
+ *           crn_comm_allgather(c, i, stream)     -> returns at once; the gather runs on the side stream
+ *           ... crn_comm_gathered(c, i, &all)    valid once `stream` has passed crn_comm_finish / the
+ *                                                crn_comm_local of step i + depth
+ * RCCL is loaded at run time by crn_comm_unique_id / crn_comm_create (librccl.so.1, or $CRN_RCCL_LIB):
+ * single-GPU users of libcrnsense do not need it. */
+typedef struct crn_comm crn_comm;
+#define CRN_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+
+CRN_API int crn_comm_unique_id(uint8_t id[CRN_COMM_ID_BYTES]);
+/* Collective over all `world` ranks (blocks until every rank has called it).  Allocates, once, the
+ * `depth` local and gathered slots on `device` and a private side stream. */
+CRN_API int crn_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[CRN_COMM_ID_BYTES],
+                            int64_t bytes_per_rank, int32_t depth, crn_comm **out);
+/* Device address of the block step `step` writes (slot step % depth).  If that slot's previous gather
+ * is still in flight, `stream` is made to wait for it (on the device; the host does not block). */
+CRN_API int crn_comm_local(crn_comm *c, int64_t step, void *stream, uint8_t **d_local);
+/* Queue the all-gather of step `step`'s block behind everything enqueued on `stream` so far.  Only enqueues. */
+CRN_API int crn_comm_allgather(crn_comm *c, int64_t step, void *stream);
+/* Device address of step `step`'s gathered vector, [world][bytes_per_rank], rank order. */
+CRN_API int crn_comm_gathered(crn_comm *c, int64_t step, const uint8_t **d_all);
+/* Make `stream` wait for every gather queued so far (call before the final synchronise). */
+CRN_API int crn_comm_finish(crn_comm *c, void *stream);
+CRN_API int crn_comm_destroy(crn_comm *c);
+
 /* -- the transform on its own ------------------------------------------------------------------
  * Unnormalised forward DFT X[k] = sum_n x[n] exp(-j 2 pi k n / N) (the contract of liquid-dsp's
  * fft_execute with LIQUID_FFT_FORWARD, CE_Predictive_Node.cpp:42-45,150) of n_frames frames:

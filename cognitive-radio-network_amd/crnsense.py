@@ -30,6 +30,8 @@ EXPORTS = [
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
     "crn_sense_reserve_host",
+    "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
+    "crn_comm_finish", "crn_comm_destroy",
     "crn_last_error", "crn_abi_version",
 ]
 
@@ -125,6 +127,14 @@ def lib():
         L.crn_ingest_wait.argtypes = [C.c_void_p]
         L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.crn_comm_unique_id.argtypes = [C.c_void_p]
+        L.crn_comm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                      C.POINTER(C.c_void_p)]
+        L.crn_comm_local.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.crn_comm_allgather.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.crn_comm_gathered.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.crn_comm_finish.argtypes = [C.c_void_p, C.c_void_p]
+        L.crn_comm_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -262,6 +272,63 @@ def set_ann_weights(cfg, w_ih, w_ho, threshold=0.8):
     cfg.ann_threshold = threshold
     cfg.decide = DECIDE_ANN
     return cfg
+
+
+COMM_ID_BYTES = 128
+
+_hip = None
+
+
+def device_to_host(ptr, nbytes):
+    """Blocking copy of device memory at raw address `ptr` into a bytes object (plumbing for checks)."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    buf = (C.c_uint8 * nbytes)()
+    rc = _hip.hipMemcpy(buf, C.c_void_p(ptr), nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise CrnError(f"hipMemcpy D2H failed ({rc})")
+    return bytes(buf)
+
+
+def comm_unique_id():
+    """bytes(128): call on rank 0, hand to the other ranks out of band."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().crn_comm_unique_id(buf), "crn_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """The occupancy exchange over RCCL (crn_comm_* in include/crn_sense.h): `depth` slots of
+    bytes_per_rank on `device`, all-gathers queued on a side stream."""
+
+    def __init__(self, device, rank, world, unique_id, bytes_per_rank, depth=2):
+        self.rank, self.world, self.bytes, self.depth = rank, world, bytes_per_rank, depth
+        self._c = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().crn_comm_create(device, rank, world, buf, bytes_per_rank, depth, C.byref(self._c)), "crn_comm_create")
+
+    def local(self, step, stream=0):
+        p = C.c_void_p()
+        check(lib().crn_comm_local(self._c, step, C.c_void_p(stream or None), C.byref(p)), "crn_comm_local")
+        return p.value
+
+    def allgather(self, step, stream=0):
+        check(lib().crn_comm_allgather(self._c, step, C.c_void_p(stream or None)), "crn_comm_allgather")
+
+    def gathered(self, step):
+        p = C.c_void_p()
+        check(lib().crn_comm_gathered(self._c, step, C.byref(p)), "crn_comm_gathered")
+        return p.value
+
+    def finish(self, stream=0):
+        check(lib().crn_comm_finish(self._c, C.c_void_p(stream or None)), "crn_comm_finish")
+
+    def close(self):
+        if self._c:
+            lib().crn_comm_destroy(self._c)
+            self._c = C.c_void_p()
 
 
 class Ingest:

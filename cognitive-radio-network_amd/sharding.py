@@ -4,8 +4,13 @@ Every (stream, epoch) is independent — the only state that crosses frames is t
 inside one epoch of one stream (reference: fft_avg[], CE_Predictive_Node.hpp:51) — so the path
 shards by stream with no data-path collective.  The one exchange is the occupancy vector: every
 node's engine needs the full picture to pick a free channel, so each rank contributes its
-[epochs, n_bands] uint8 block to an all-gather (RCCL over xGMI on the GPU box; gloo in CPU tests).
-Messages are a few KiB: latency-bound, one collective per batch.
+[epochs, n_bands] uint8 block to an all-gather.  Messages are a few KiB: latency-bound, one
+collective per batch.
+
+On the GPU the exchange is the C ABI's (`crn_comm_*` in include/crn_sense.h: RCCL over xGMI, side
+stream, double-buffered slots) — `DeviceOccupancyExchange` below only carries the RCCL unique id
+from rank 0 to the others over the launcher's control group (gloo).  `OccupancyExchange` is the same
+slot logic on CPU tensors over gloo, for the world-size-2 layout tests that run without a GPU.
 """
 import torch.distributed as dist
 
@@ -17,11 +22,10 @@ def shard(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_occupancy(occ_local, occ_all=None, force=False):
-    """All-gather equal-sized per-rank occupancy blocks; returns the [world * epochs, n_bands] tensor.
-    `force` runs the collective even in a group of one rank (single-GPU dry run of the N>1 path)."""
+def gather_occupancy(occ_local, occ_all=None):
+    """All-gather equal-sized per-rank occupancy blocks (CPU tensors, gloo); returns [world * epochs, n_bands]."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1 and not (force and dist.is_initialized()):
+    if world == 1:
         return occ_local
     if occ_all is None:
         occ_all = occ_local.new_empty((world * occ_local.shape[0],) + tuple(occ_local.shape[1:]))
@@ -30,64 +34,70 @@ def gather_occupancy(occ_local, occ_all=None, force=False):
 
 
 class OccupancyExchange:
-    """Double-buffered occupancy all-gather that overlaps the next launch.
+    """CPU twin (gloo) of the slot logic of crn_comm_*: step i writes slot i % depth (`local(i)`),
+    `exchange(i)` gathers it; used by tests/test_sharding_gloo.py."""
 
-    Step i writes its occupancy block into slot i % depth (`local(i)`), then `exchange(i)` queues
-    the all-gather of that slot on a side stream behind an event, so the sensing kernel of step
-    i + 1 starts without waiting for the collective (a few KiB per rank over xGMI: latency, not
-    bandwidth).  A slot is handed out again only after its previous gather has finished
-    (`local()` makes the launch stream wait for it).  On CPU tensors (gloo tests) the same calls
-    run synchronously.
-    """
-
-    def __init__(self, epochs, n_bands, device, depth=2):
+    def __init__(self, epochs, n_bands, device="cpu", depth=2):
         import torch
-        self._torch = torch
+        if torch.device(device).type != "cpu":
+            raise ValueError("on the GPU use DeviceOccupancyExchange (the C ABI's crn_comm_*)")
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.depth = depth
-        self.cuda = torch.device(device).type == "cuda"
-        self.local_bufs = [torch.empty(epochs, n_bands, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.all_bufs = [torch.empty(self.world * epochs, n_bands, dtype=torch.uint8, device=device)
-                         for _ in range(depth)]
-        if self.cuda:
-            self.side = torch.cuda.Stream(device=device)
-            self.ready = [torch.cuda.Event() for _ in range(depth)]   # launch stream: block written
-            self.done = [torch.cuda.Event() for _ in range(depth)]    # side stream: gather finished
-            self.pending = [False] * depth
+        self.local_bufs = [torch.empty(epochs, n_bands, dtype=torch.uint8) for _ in range(depth)]
+        self.all_bufs = [torch.empty(self.world * epochs, n_bands, dtype=torch.uint8) for _ in range(depth)]
 
     def local(self, i):
-        """Block step i's kernel writes (waits, on the launch stream, for the slot's last gather)."""
-        s = i % self.depth
-        if self.cuda and self.pending[s]:
-            self._torch.cuda.current_stream().wait_event(self.done[s])
-            self.pending[s] = False
-        return self.local_bufs[s]
+        return self.local_bufs[i % self.depth]
 
     def exchange(self, i):
-        """Queue the all-gather of step i's block; returns the (eventually) gathered tensor."""
         s = i % self.depth
         if not dist.is_initialized():
             self.all_bufs[s].copy_(self.local_bufs[s])
-            return self.all_bufs[s]
-        if not self.cuda:
+        else:
             dist.all_gather_into_tensor(self.all_bufs[s], self.local_bufs[s])
-            return self.all_bufs[s]
-        torch = self._torch
-        self.ready[s].record(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ready[s])
-            dist.all_gather_into_tensor(self.all_bufs[s], self.local_bufs[s])
-            self.done[s].record(self.side)
-        self.pending[s] = True
         return self.all_bufs[s]
 
     def gathered(self, i):
         return self.all_bufs[i % self.depth]
 
     def finish(self):
-        """Make the launch stream wait for every queued gather (call before the final synchronize)."""
-        if self.cuda:
-            for s in range(self.depth):
-                if self.pending[s]:
-                    self._torch.cuda.current_stream().wait_event(self.done[s])
-                    self.pending[s] = False
+        pass
+
+
+class DeviceOccupancyExchange:
+    """The occupancy exchange on the GPU: libcrnsense's crn_comm_* (RCCL all-gather on a side stream,
+    `depth` slots).  rank / world come from the launcher (torch.distributed.run); the RCCL unique id is
+    created on rank 0 through the C ABI and broadcast over the control group (any backend: gloo here)."""
+
+    def __init__(self, epochs, n_bands, device_index, rank, world, depth=2):
+        import crnsense as cs
+        self.cs = cs
+        self.epochs, self.n_bands, self.rank, self.world, self.depth = epochs, n_bands, rank, world, depth
+        box = [cs.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self.comm = cs.Comm(device_index, rank, world, box[0], epochs * n_bands, depth)
+
+    def local_ptr(self, i, stream):
+        """Device address step i's kernel writes its occupancy block to."""
+        return self.comm.local(i, stream)
+
+    def exchange(self, i, stream):
+        self.comm.allgather(i, stream)
+
+    def finish(self, stream):
+        self.comm.finish(stream)
+
+    def gathered_host(self, i):
+        """Step i's gathered vector as a numpy [world * epochs, n_bands] array (after a synchronise)."""
+        import numpy as np
+        raw = self.cs.device_to_host(self.comm.gathered(i), self.world * self.epochs * self.n_bands)
+        return np.frombuffer(raw, dtype=np.uint8).reshape(self.world * self.epochs, self.n_bands)
+
+    def local_host(self, i):
+        import numpy as np
+        raw = self.cs.device_to_host(self.comm.local(i, 0), self.epochs * self.n_bands)
+        return np.frombuffer(raw, dtype=np.uint8).reshape(self.epochs, self.n_bands)
+
+    def close(self):
+        self.comm.close()

@@ -38,6 +38,28 @@ def lib():
     return _lib
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: switch to a -O2 -march=native build of the same sources, compiled here and now
+    (oracle/_native/, `make -C oracle native`).  Returns False — and keeps the portable build — if that fails."""
+    global _lib, ORACLE_LIB
+    path = os.path.join(ORACLE_DIR, "_native", "libcrn_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    if not os.path.exists(path):
+        return False
+    ORACLE_LIB = path
+    _lib = None
+    try:
+        lib()
+    except Exception:
+        ORACLE_LIB = os.path.join(ORACLE_DIR, "libcrn_oracle.so")
+        _lib = None
+        return False
+    return True
+
+
 def fft_radix2(x):
     """x: complex64 [N] -> complex64 [N] (liquid-dsp style fp32 radix-2 DIT)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)

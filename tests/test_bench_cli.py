@@ -32,6 +32,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "epochs" in c["sample"]
+    assert c["one_thread"]["cores"] == 1 and c["one_thread"]["value"] > 0
+    assert r["events"] == "per-launch" and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"]
+    assert d["metric"].startswith("Msamples/s IQ through FFT+energy-detect, 4096-pt x 3ch")
     assert d["config"]["workload"].startswith("4096-pt")
 
 
@@ -40,3 +43,6 @@ def test_bench_collective_path_on_one_gpu(built, mode):
     d = _run("--cpu-epochs", "0", "--force-collective", *mode)
     assert "RCCL all-gather of occupancy" in d["config"]["parallelism"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    if "welch" in mode or "scan" in mode:
+        assert d["roofline_valu"]["bound"] == "valu" and 0 < d["roofline_valu"]["frac"] < 1
+        assert "Welch" in d["metric"]

@@ -1,0 +1,63 @@
+"""The occupancy exchange through the C ABI (crn_comm_* in include/crn_sense.h: RCCL all-gather on a side
+stream, `depth` slots).  On the GPU box: a one-rank communicator end to end (create, slot hand-out, gather,
+slot reuse, ordering against the launch stream) and the sensing kernel writing straight into a slot.  Without a
+GPU: the entry points fail cleanly.  The two-rank layout (rank order, slot reuse) is covered on CPU by
+tests/test_sharding_gloo.py with the gloo twin of the same slot logic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import crnsense as cs
+
+
+def test_comm_fails_cleanly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    try:                      # whether RCCL hands out an id without a device depends on its version:
+        uid = cs.comm_unique_id()   # either a 128-byte id ...
+        assert len(uid) == cs.COMM_ID_BYTES
+    except cs.CrnError:       # ... or a clean error; creating a communicator must fail cleanly either way
+        pass
+    c = C.c_void_p()
+    rc = cs.lib().crn_comm_create(0, 0, 1, (C.c_uint8 * 128)(), 64, 2, C.byref(c))
+    assert rc < 0 and not c.value
+    assert cs.lib().crn_comm_create(0, 3, 2, (C.c_uint8 * 128)(), 64, 2, C.byref(c)) == -1   # rank >= world
+
+
+@pytest.mark.gpu
+def test_one_rank_communicator_end_to_end(built):
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    cfg = cs.cfg_reference()
+    E = 64
+    comm = cs.Comm(0, 0, 1, cs.comm_unique_id(), E * cfg.n_bands, depth=2)
+    sensor = cs.Sensor(cfg)
+    spe = cs.samples_per_epoch(cfg)
+    iq = torch.zeros(E * spe * 2, dtype=torch.float32, device=dev)
+    truth = torch.empty(E, dtype=torch.int32, device=dev)
+    dec = torch.empty(E, dtype=torch.int32, device=dev)
+    ptrs = set()
+    for step in range(5):                      # more steps than slots: both slots are reused
+        sensor.synth_fill_device(iq.data_ptr(), E, spe, seed=100 + step, truth_ptr=truth.data_ptr(), stream=stream)
+        occ_ptr = comm.local(step, stream)     # makes `stream` wait for this slot's previous gather
+        ptrs.add(occ_ptr)
+        sensor.run_device(iq.data_ptr(), E, 512, {"features": 0, "ann_out": 0, "decision": dec.data_ptr(),
+                                                  "occupancy": occ_ptr, "spectrum": 0}, stream=stream)
+        comm.allgather(step, stream)           # only enqueues: side stream, behind an event of `stream`
+        comm.finish(stream)
+        torch.cuda.synchronize()
+        got = np.frombuffer(cs.device_to_host(comm.gathered(step), E * cfg.n_bands), np.uint8).reshape(E, cfg.n_bands)
+        picks = truth.cpu().numpy()
+        want = np.zeros((E, cfg.n_bands), np.uint8)
+        want[np.nonzero(picks)[0], picks[picks > 0]] = 1     # one-hot over bands 1..3 from the decision
+        assert np.array_equal(got, want), step
+        assert np.array_equal(dec.cpu().numpy(), picks)
+    assert len(ptrs) == 2
+    with pytest.raises(cs.CrnError):
+        comm.local(-1, stream)
+    sensor.close()
+    comm.close()
