@@ -291,6 +291,22 @@ CRN_API int crn_comm_destroy(crn_comm *c);
 CRN_API int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, int32_t samples_per_frame,
                                    int64_t frame_stride, float *d_out, void *stream);
 
+/* -- monitor rows -----------------------------------------------------------
+ * The display side of the reference's GNU Radio monitor — qtgui.freq_sink_c(fft_size 1024,
+ * firdes.WIN_BLACKMAN_hARRIS), set_fft_average(0.1), and the waterfall sink (spectrum_analyzer.py:262-275) —
+ * over rows of the `spectrum` output of crn_sense_run_device (window CRN_WINDOW_BLACKMAN_HARRIS, mode
+ * CRN_MODE_ENERGY; frames_per_epoch frames per row, 1 for the sink's one-FFT-per-update):
+ *   d_waterfall_db[r][j]  10 log10(P_r[(j + N/2) mod N] / norm)         fftshifted, like the sinks draw it
+ *   d_average_db[r][j]    the single-pole IIR over rows, a = alpha:  y <- (1 - a) y + a x
+ *   d_state[j]            the IIR state, carried between calls (first != 0: seeded with row 0)
+ * CRN_MONITOR_GNURADIO: norm = N^2 and the IIR runs on the dB values (gr-qtgui 3.7 freq_sink_c_impl.cc: volk
+ *   power_spectral_density then d_magbuf = (1 - a) d_magbuf + a new — GNU Radio is third-party and absent from
+ *   the reference tree; this is its published algorithm).
+ * CRN_MONITOR_PSD: norm = N * sum(w^2) and the IIR runs on linear power (a Welch-style averaged PSD), dB after. */
+typedef enum crn_monitor_kind { CRN_MONITOR_GNURADIO = 0, CRN_MONITOR_PSD = 1 } crn_monitor_kind;
+CRN_API int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,
+                                    int32_t first, float *d_state, float *d_waterfall_db, float *d_average_db, void *stream);
+
 /* -- training -------------------------------------------------------------
  * The reference ships weights for one FFT size and one receiver gain (CE_Predictive_Node.cpp:78-120)
  * and no way to make others.  crn_ann_train_device fits the same 4-5-3 sigmoid network

@@ -30,6 +30,7 @@ EXPORTS = [
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
     "crn_sense_reserve_host",
+    "crn_monitor_rows_device",
     "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
     "crn_comm_finish", "crn_comm_destroy",
     "crn_last_error", "crn_abi_version",
@@ -66,6 +67,7 @@ class EpochResult(C.Structure):
                 ("occupancy", C.c_uint8 * CRN_MAX_BANDS)]
 
 
+MONITOR_GNURADIO, MONITOR_PSD = 0, 1
 PU_UNIFORM, PU_MARKOV_AS_WRITTEN, PU_MARKOV_INTENDED = 0, 1, 2
 SIG_TONES, SIG_CW, SIG_BAND_NOISE = 0, 1, 2
 
@@ -127,6 +129,8 @@ def lib():
         L.crn_ingest_wait.argtypes = [C.c_void_p]
         L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.crn_monitor_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.crn_comm_unique_id.argtypes = [C.c_void_p]
         L.crn_comm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                       C.POINTER(C.c_void_p)]
@@ -249,6 +253,12 @@ class Sensor:
         """Unnormalised forward DFT of n_frames frames (device pointers)."""
         check(lib().crn_fft_forward_device(self._h, in_ptr, n_frames, L, frame_stride, out_ptr,
                                            C.c_void_p(stream or None)), "crn_fft_forward_device")
+
+    def monitor_rows_device(self, spec_ptr, n_rows, kind, alpha, first, state_ptr, waterfall_ptr=0, average_ptr=0, stream=0):
+        """fftshifted dB rows + IIR-averaged trace from rows of the `spectrum` output (device pointers)."""
+        check(lib().crn_monitor_rows_device(self._h, spec_ptr, n_rows, kind, alpha, int(first), state_ptr,
+                                            C.c_void_p(waterfall_ptr or None), C.c_void_p(average_ptr or None),
+                                            C.c_void_p(stream or None)), "crn_monitor_rows_device")
 
     def ann_train_device(self, tc, feat_ptr, label_ptr, n, stream=0):
         """Fit the 4-5-3 network to device-resident features/labels; returns (w_ih, w_ho, loss)."""

@@ -44,6 +44,7 @@ struct crn_handle {
   // scratch of crn_sense_run_host
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  double window_power = 0.0;   // sum of the squared fp32 window values (crn_monitor_rows_device)
   void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
   size_t h_results_bytes = 0;
 };
@@ -120,6 +121,8 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
       const double x = 2.0 * M_PI * (double)n / (double)(N - 1);
       win[n] = (float)(0.35875 - 0.48829 * std::cos(x) + 0.14128 * std::cos(2 * x) - 0.01168 * std::cos(3 * x));
     }
+
+  for (int n = 0; n < N; n++) h->window_power += (double)win[n] * (double)win[n];
 
   // segments grouped by band, table order kept inside a band (the reference sums CH1's two runs
   // in table order, CE_Predictive_Node.cpp:173-179)
@@ -442,6 +445,29 @@ int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t want_spect
   o.features = feat.data();
   o.spectrum = want_spectrum ? spec.data() : nullptr;
   return crn_sense_run_host(h, zeros.data(), max_epochs, c.fft_len, 0, &o);
+}
+
+int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,
+                            int32_t first, float *d_state, float *d_waterfall_db, float *d_average_db, void *stream) {
+  if (!h || !d_spectrum || !d_state) return crn::fail(CRN_ERR_ARG, "null handle / spectrum / state");
+  if (n_rows < 0) return crn::fail(CRN_ERR_ARG, "n_rows < 0");
+  if (kind != CRN_MONITOR_GNURADIO && kind != CRN_MONITOR_PSD) return crn::fail(CRN_ERR_ARG, "unknown monitor kind");
+  if (!(alpha > 0.f && alpha <= 1.f)) return crn::fail(CRN_ERR_ARG, "alpha must be in (0, 1]");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const double N = (double)h->cfg.fft_len;
+  crn::MonitorParams p{};
+  p.spectrum = d_spectrum;
+  p.n_rows = n_rows;
+  p.n = h->cfg.fft_len;
+  p.alpha = alpha;
+  p.scale = (float)(1.0 / (kind == CRN_MONITOR_GNURADIO ? N * N : N * h->window_power));
+  p.db_domain = kind == CRN_MONITOR_GNURADIO;
+  p.first = first != 0;
+  p.state = d_state;
+  p.waterfall_db = d_waterfall_db;
+  p.average_db = d_average_db;
+  HIP_TRY(crn::launch_monitor(p, static_cast<hipStream_t>(stream)));
+  return CRN_OK;
 }
 
 int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, int32_t samples_per_frame,

@@ -87,6 +87,19 @@ struct FftParams {
   const float2 *tw2;       // [16][R3]
 };
 hipError_t launch_fft(const FftParams &p, int fft_len, hipStream_t stream);
+struct MonitorParams {
+  const float *spectrum;   // [n_rows][n] the sensing kernel's per-bin output (mean |X|^2 over the row's frames)
+  long long n_rows;
+  int n;                   // fft_len (power of two)
+  float alpha;             // IIR weight of the new row
+  float scale;             // 1 / normalisation of |X|^2
+  int db_domain;           // 1: average the dB values (gr-qtgui); 0: average linear power
+  int first;               // 1: the state is seeded with row 0
+  float *state;            // [n] IIR state per displayed column, in / out
+  float *waterfall_db;     // [n_rows][n] or null
+  float *average_db;       // [n_rows][n] or null
+};
+hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 

@@ -1,0 +1,41 @@
+// crn_monitor.hip — the display side of the reference's GNU Radio monitor on the device
+// (reference: spectrum_analyzer.py:262-275: qtgui.freq_sink_c(fft_size = 1024, firdes.WIN_BLACKMAN_hARRIS, ..),
+// set_fft_average(0.1), plus the waterfall sink).  The windowed FFT + |X|^2 (+ K-frame mean) is the sensing
+// kernel's `spectrum` output; this epilogue turns those rows into what the sinks draw: fftshifted dB rows (the
+// waterfall) and the single-pole-IIR averaged trace, with the IIR state kept on the device between calls.
+//
+// GNU Radio itself is a third-party dependency absent from the reference tree; its published algorithm
+// (gr-qtgui 3.7, freq_sink_c_impl.cc: window multiply -> FFT -> volk power_spectral_density
+// 10 log10(|X / N|^2) -> fftshift -> d_magbuf = (1 - a) d_magbuf + a new, on the dB values) is what
+// CRN_MONITOR_GNURADIO restates; CRN_MONITOR_PSD averages linear power normalised by N sum(w^2) instead.
+#include <hip/hip_runtime.h>
+
+#include "crn_kernels.h"
+
+namespace crn {
+
+// One thread per displayed column j (bin (j + N/2) mod N): rows are walked in order because the IIR is.
+__global__ __launch_bounds__(256) void monitor_rows_kernel(const MonitorParams p) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.n) return;
+  const int src = (j + p.n / 2) & (p.n - 1);   // fftshift: the centre frequency in the middle, like the sinks
+  const float floor_p = 1e-30f;
+  float acc = p.first ? 0.f : p.state[j];
+  for (long long r = 0; r < p.n_rows; r++) {
+    const float pw = p.spectrum[r * p.n + src] * p.scale;
+    const float db = 10.0f * log10f(fmaxf(pw, floor_p));
+    if (p.waterfall_db != nullptr) p.waterfall_db[r * p.n + j] = db;
+    const float v = p.db_domain ? db : pw;
+    acc = (p.first && r == 0) ? v : fmaf(p.alpha, v - acc, acc);   // (1 - a) acc + a v
+    if (p.average_db != nullptr) p.average_db[r * p.n + j] = p.db_domain ? acc : 10.0f * log10f(fmaxf(acc, floor_p));
+  }
+  p.state[j] = acc;
+}
+
+hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream) {
+  if (p.n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(monitor_rows_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace crn

@@ -1,0 +1,65 @@
+"""SURVEY.md §8(f)-4, the spectrum-analyser counterpart: tools/spectrum_monitor.py driven on a synthetic
+capture, against an independent float64 numpy statement of what the reference's GNU Radio flowgraph draws
+(spectrum_analyzer.py:262-275: freq_sink_c(1024, Blackman-Harris), set_fft_average(0.1), waterfall): window
+multiply -> FFT -> 10 log10(|X / N|^2) -> fftshift -> single-pole IIR over updates."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _capture(n_rows, fft, frames, seed):
+    rng = np.random.default_rng(seed)
+    n = n_rows * frames * fft
+    t = np.arange(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 1e-3
+    x += 0.02 * np.exp(2j * np.pi * (100.3 / fft) * t)                         # an off-grid carrier (window leakage matters)
+    x[n // 2:] += 0.05 * np.exp(2j * np.pi * (-200.0 / fft) * t[n // 2:])      # a second one that appears half way
+    return x.astype(np.complex64)
+
+
+def _reference(x, fft, frames, alpha, kind):
+    i = np.arange(fft)
+    th = 2 * np.pi * i / (fft - 1)
+    w = (0.35875 - 0.48829 * np.cos(th) + 0.14128 * np.cos(2 * th) - 0.01168 * np.cos(3 * th)).astype(np.float32).astype(np.float64)
+    rows = x.astype(np.complex128).reshape(-1, frames, fft)
+    p = (np.abs(np.fft.fft(rows * w, axis=2)) ** 2).mean(axis=1)
+    p = np.fft.fftshift(p, axes=1) / (fft ** 2 if kind == "gnuradio" else fft * np.sum(w * w))
+    water = 10 * np.log10(np.maximum(p, 1e-30))
+    v = water if kind == "gnuradio" else p
+    avg = np.empty_like(v)
+    acc = v[0].copy()
+    for r in range(v.shape[0]):
+        acc = v[r] if r == 0 else (1 - alpha) * acc + alpha * v[r]
+        avg[r] = acc
+    return water, (avg if kind == "gnuradio" else 10 * np.log10(np.maximum(avg, 1e-30)))
+
+
+@pytest.mark.parametrize("kind,fft,frames,chunk", [("gnuradio", 1024, 1, 7), ("psd", 1024, 4, 4096), ("gnuradio", 4096, 2, 5)])
+def test_spectrum_monitor_tool_matches_float64(built, tmp_path, kind, fft, frames, chunk):
+    n_rows, alpha = 23, 0.1
+    x = _capture(n_rows, fft, frames, seed=fft + frames)
+    cap = tmp_path / "capture.c64"
+    x.tofile(cap)
+    out = tmp_path / "psd.npz"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spectrum_monitor.py"), str(cap), "--fft", str(fft), "--frames",
+                        str(frames), "--alpha", str(alpha), "--kind", kind, "--chunk-rows", str(chunk), "--out", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    water, avg = _reference(x, fft, frames, alpha, kind)
+    assert got["waterfall_db"].shape == (n_rows, fft)
+    # bins well above the fp32 noise of the transform: 1e-3 dB; every bin: 0.05 dB (relative 1e-2 of a near-empty bin)
+    strong = water > water.max() - 90
+    assert np.abs(got["waterfall_db"] - water)[strong].max() < 2e-3
+    assert np.abs(got["average_db"] - avg)[strong].max() < 2e-3
+    assert np.abs(got["waterfall_db"] - water).max() < 0.1 and np.abs(got["average_db"] - avg).max() < 0.1
+    # what the display shows: the carrier that appears half way rises with the IIR's time constant
+    col = fft // 2 - 200
+    assert got["average_db"][n_rows // 2 - 1, col] < got["average_db"][-1, col] - 10
+    assert "peak bin of last averaged row" in r.stdout
