@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--span-events", action="store_true",
                     help="one event pair around all timed launches instead of one pair per launch")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
+    ap.add_argument("--zeros", action="store_true",
+                    help="diagnostic, not a result: all-zero IQ (same instruction stream, least switching energy) — how much "
+                         "of the kernel time is the clock the chip holds under load (implies --no-check, no CPU baseline)")
     ap.add_argument("--force-collective", action="store_true",
                     help="dry run of the N>1 code path on one GPU: RCCL group of one rank, all-gather every step")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
@@ -166,8 +169,13 @@ def main():
     dec = torch.empty(E, dtype=torch.int32, device=dev)
     ann = torch.empty(E, 3, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    sensor.synth_fill_device(iq.data_ptr(), E, spe, seed=0xC0FFEE + 1000 * rank, truth_ptr=truth.data_ptr(),
-                             stream=stream)
+    if args.zeros:
+        args.no_check, args.cpu_epochs, args.no_alt = True, 0, True
+        truth.zero_()
+        workload += " [DIAGNOSTIC: all-zero input]"
+    else:
+        sensor.synth_fill_device(iq.data_ptr(), E, spe, seed=0xC0FFEE + 1000 * rank, truth_ptr=truth.data_ptr(),
+                                 stream=stream)
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
     # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the

@@ -358,6 +358,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.n_bands = c.n_bands;
   p.decide = c.decide;
   p.ref_band = c.ref_band;
+  p.hann_sym = c.window == CRN_WINDOW_HANN;
   p.row_mask = h->row_mask;
   p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;

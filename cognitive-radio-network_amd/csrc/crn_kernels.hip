@@ -88,6 +88,21 @@ struct M {
       return cx{fmaf(a.y, w.y, a.x * w.x), fmaf(-a.x, w.y, a.y * w.x)};
     }
   }
+  // w_S * t + x (NEG: w_S * t - x), w_S = half S of the register pair wp: a real weight applied to a complex value
+  template <int S, bool NEG>
+  CRN_DEV cx fma_w(cx wp, cx t, cx x) {
+    if constexpr (PK) {
+      cx d;
+      if constexpr (S == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(wp), "v"(t), "v"(x));
+      if constexpr (S == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(wp), "v"(t), "v"(x));
+      if constexpr (S == 0 && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(wp), "v"(t), "v"(x));
+      if constexpr (S == 1 && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(wp), "v"(t), "v"(x));
+      return d;
+    } else {
+      const float w = S == 0 ? wp.x : wp.y;
+      return NEG ? cx{fmaf(w, t.x, -x.x), fmaf(w, t.y, -x.y)} : cx{fmaf(w, t.x, x.x), fmaf(w, t.y, x.y)};
+    }
+  }
   // a * w, w a wave-uniform constant held in an SGPR pair
   CRN_DEV cx mul_c(cx a, cx w) {
     if constexpr (PK) {
@@ -101,6 +116,19 @@ struct M {
     }
   }
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int I, int N, class F>
+CRN_DEV void static_for_(F &f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+CRN_DEV void static_for(F &&f) {
+  static_for_<0, N>(f);
+}
 
 #define CRN_C1 0.92387953251128674f  // cos(pi/8)
 #define CRN_S1 0.38268343236508977f  // sin(pi/8)
@@ -123,20 +151,10 @@ struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-// 16-point forward DFT, natural order in and out, as 4 x 4.  `hook(k)`, k = 0..7, runs after the
-// k-th radix-4 group: the caller uses it to drop one prefetch load into the butterfly stream.
+// Twiddles W16^{r0 a0} and level B of the 16-point transform (shared by the plain and the windowed level A).
 template <bool PK, class Hook = NoHook>
-CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook()) {
+CRN_DEV void dft16_level_b(cx (&y)[16], cx (&out)[16], const Hook &hook = Hook()) {
   using m = M<PK>;
-  cx y[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) y[i] = in[i];
-  // level A: for each r0, DFT4 over r1 (r = r0 + 4 r1); a0 replaces r1
-#pragma unroll
-  for (int r0 = 0; r0 < 4; r0++) {
-    dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
-    hook(r0);
-  }
   // W16^{r0 a0} on element (r0, a0) = y[r0 + 4 a0]; W16^4 = -j is folded into level B
   const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
   const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
@@ -161,6 +179,52 @@ CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook())
   for (int a0 = 0; a0 < 4; a0++)
 #pragma unroll
     for (int a1 = 0; a1 < 4; a1++) out[a0 + 4 * a1] = y[a1 + 4 * a0];
+}
+
+// 16-point forward DFT, natural order in and out, as 4 x 4.  `hook(k)`, k = 0..7, runs after the
+// k-th radix-4 group: the caller uses it to drop one prefetch load into the butterfly stream.
+template <bool PK, class Hook = NoHook>
+CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook()) {
+  cx y[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = in[i];
+  // level A: for each r0, DFT4 over r1 (r = r0 + 4 r1); a0 replaces r1
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0++) {
+    dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+    hook(r0);
+  }
+  dft16_level_b<PK>(y, out, hook);
+}
+
+// The same transform with a periodic Hann window folded into level A.  Rows r and r + 8 of a thread are
+// samples n and n + N/2, where the window satisfies w[n + N/2] = 1 - w[n], so the first butterfly of the
+// pair (x_lo, x_hi) needs one weight:
+//   w x_lo + (1 - w) x_hi = w (x_lo - x_hi) + x_hi        w x_lo - (1 - w) x_hi = w (x_lo + x_hi) - x_hi
+// — two packed adds and two packed FMAs per pair, the cycles of the 4 multiplies + 2 adds they replace in
+// a third fewer instructions, and 8 window registers instead of 16.  wp[p] = (w[2p], w[2p + 1]), rows 0..7.
+template <bool PK, class Hook = NoHook>
+CRN_DEV void dft16_hann(const cx (&in)[16], cx (&out)[16], const cx (&wp)[4], const Hook &hook = Hook()) {
+  using m = M<PK>;
+  cx y[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = in[i];
+  static_for<4>([&](auto rc) {
+    constexpr int r0 = decltype(rc)::value;
+    constexpr int S = r0 & 1;
+    const cx x0 = y[r0], x1 = y[r0 + 4], x2 = y[r0 + 8], x3 = y[r0 + 12];
+    const cx w0 = wp[r0 / 2], w1 = wp[(r0 + 4) / 2];
+    const cx s02 = m::template fma_w<S, false>(w0, m::sub(x0, x2), x2);
+    const cx d02 = m::template fma_w<S, true>(w0, m::add(x0, x2), x2);
+    const cx s13 = m::template fma_w<S, false>(w1, m::sub(x1, x3), x3);
+    const cx d13 = m::template fma_w<S, true>(w1, m::add(x1, x3), x3);
+    y[r0] = m::add(s02, s13);
+    y[r0 + 8] = m::sub(s02, s13);
+    y[r0 + 4] = m::add_mj(d02, d13);
+    y[r0 + 12] = m::sub_mj(d02, d13);
+    hook(r0);
+  });
+  dft16_level_b<PK>(y, out, hook);
 }
 
 // The reference hard-codes its channel plan (bins 0-15 + 496-510, 55-84, 189-221, 300-309 of 512:
@@ -320,6 +384,8 @@ enum : int {
   kNoClose = 2048,  // measurement ablation: the epoch close only folds and resets the accumulators
   kTrace = 4096,    // measurement aid: s_memtime at epoch-close entry / exit into the ann_out buffer
   kRegBands = 8192, // epoch close forms the band sums from registers (plans with n_row_entries > 0, no spectrum)
+  kHannSym = 16384, // periodic Hann folded into pass 1's first butterflies (w[n + N/2] = 1 - w[n]): 8 window registers
+  kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -337,6 +403,7 @@ struct FrameCtx {
   cx tw1[16];   // W_N^{t i}
   cx tw2[16];   // W_T^{m_lo i} (registers unless TW2LDS)
   float win[16];
+  cx winp[4];   // kHannSym: (w[2p], w[2p + 1]) of rows 0..7
   float acc[16];
   const cx *tw2_lds;
   int wave;           // wave index in the workgroup (SGPR)
@@ -375,11 +442,15 @@ template <class C, class Hook = NoHook>
 CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
   if constexpr (!C::FULL) mask_frame<C::R3>(u, c.t, c.L);
-  if constexpr (C::WIN) {
+  if constexpr (C::WIN && (C::OPT & kHannSym) != 0) {
+    dft16_hann<C::PK>(u, v, c.winp, hook);
+  } else {
+    if constexpr (C::WIN) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
+      for (int r = 0; r < 16; r++) u[r] = cx{u[r].x * c.win[r], u[r].y * c.win[r]};
+    }
+    dft16<C::PK>(u, v, hook);
   }
-  dft16<C::PK>(u, v, hook);
   if constexpr ((C::OPT & kTw1C) != 0) {
     // compressed table: tw1[1..8] = W^{t i}, tw1[0] = W^{16 t}; W^{t (16-i)} = W^{16 t} conj(W^{t i})
 #pragma unroll
@@ -438,6 +509,27 @@ CRN_DEV void lds_read8_b64(cx (&w)[8], const cx *base) {
       : "memory");
 }
 
+// The same eight reads without the wait (the caller consumes them after lds_wait8) ...
+template <int STRIDE_BYTES>
+CRN_DEV void lds_issue8_b64(cx (&w)[8], const cx *base) {
+  const unsigned addr = (unsigned)(size_t)base;
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
+      "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
+      "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16"
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+      : "v"(addr), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
+        "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES)
+      : "memory");
+}
+// ... and the wait: the registers are tied to it so that no use is scheduled above it.
+CRN_DEV void lds_wait8(cx (&w)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
+               :
+               : "memory");
+}
+
 template <class C>
 CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   const cx *row = buf + c.a * Geo<C::R3>::ROW;
@@ -452,6 +544,20 @@ CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
 template <class C, class Hook = NoHook>
 CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
+  if constexpr (C::TW2LDS && (C::OPT & kLdsBlk) != 0 && (C::OPT & kTw2Early) != 0) {
+    // rows 1..8 are in flight while the butterflies run; rows 8..15 while rows 1..8 are applied
+    cx wa[8], wb[8];
+    lds_issue8_b64<C::R3 * 8>(wa, c.tw2_lds + 1 * C::R3 + c.m_lo);
+    dft16<C::PK>(u, v, hook);
+    lds_wait8(wa);
+    lds_issue8_b64<C::R3 * 8>(wb, c.tw2_lds + 8 * C::R3 + c.m_lo);
+#pragma unroll
+    for (int i = 1; i <= 8; i++) v[i] = m::mul(v[i], wa[i - 1]);
+    lds_wait8(wb);
+#pragma unroll
+    for (int i = 9; i < 16; i++) v[i] = m::mul(v[i], wb[i - 8]);
+    return;
+  }
   dft16<C::PK>(u, v, hook);
   if constexpr (C::TW2LDS && (C::OPT & kLdsBlk) != 0) {
     cx w[8];
@@ -691,19 +797,6 @@ CRN_DEV float team_sum(float v, int tid) {
   const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   if constexpr (TEAM == 64) return (r0 + r1) + (r2 + r3);
   else return (tid & 32) ? r2 + r3 : r0 + r1;
-}
-
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
-template <int I, int N, class F>
-CRN_DEV void static_for_(F &f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for_<I + 1, N>(f);
-  }
-}
-template <int N, class F>
-CRN_DEV void static_for(F &&f) {
-  static_for_<0, N>(f);
 }
 
 // W consecutive table words through the scalar cache into SGPRs (the epoch close must not touch
@@ -1174,7 +1267,10 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 #pragma unroll
     for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
   }
-  if constexpr (C::WIN) {
+  if constexpr (C::WIN && (C::OPT & kHannSym) != 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) c.winp[q] = cx{p.window[t + T * (2 * q)], p.window[t + T * (2 * q + 1)]};
+  } else if constexpr (C::WIN) {
 #pragma unroll
     for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
   }
@@ -1473,6 +1569,10 @@ static constexpr VariantDesc kVariants[] = {
     /* 16 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: the default with the epoch close reduced to an accumulator reset
     /* 17 */ {1, 1, 1, 1, 4, 0, 1},  // measurement aid: the default + s_memtime stamps of the epoch close in ann_out
     /* 18 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: 16 plus one workgroup barrier per epoch
+    /* 19 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: Hann folded into pass 1's first butterflies
+    /* 20 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: 19 + pass-2 twiddles read from LDS ahead of their use
+    /* 21 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: early pass-2 twiddle reads alone
+    /* 22 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the plain form (16 window registers, twiddles read where used)
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -1480,6 +1580,20 @@ static constexpr int kDefaultVariant = 13;
 // The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
+  constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
+  if (win && !mag && p.L == Geo<R3>::N && variant >= 19 && variant <= 22) {
+    // A/B set of the windowed kernel: 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2
+    // twiddle reads, 21 early twiddle reads alone, 22 the plain windowed kernel
+    if (variant == 19 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym>>(p, stream);
+    if (variant == 20 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
+    if (variant == 21) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kTw2Early>>(p, stream);
+    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase>>(p, stream);
+  }
+  // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
+  // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
+  // window registers fewer; the A/B numbers are in DESIGN.md §5)
+  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant))
+    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
   if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || (win && variant != 17) || p.L != Geo<R3>::N)
     variant = kDefaultVariant;
   // The plain 4096-point kernel runs 4 workgroups per CU with the compressed pass-1 table and pass 2
