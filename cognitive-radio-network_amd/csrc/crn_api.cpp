@@ -33,6 +33,7 @@ struct crn_handle {
   int groups_per_wg = 0;        // 0 = automatic
   int64_t tail_groups = -1;     // < 0 = automatic; epoch groups handed to single-group workgroups at the end
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
+  int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
   // one device slab holding every table
   void *d_tables = nullptr;
@@ -141,6 +142,13 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     h->row_mask = 0;
     for (int sgi = 0; sgi < cfg->n_segs; sgi++)
       for (int k = cfg->segs[sgi].lo; k < cfg->segs[sgi].hi; k++) h->row_mask |= 1u << (k >> 8);
+  }
+  if (N == 4096 && cfg->n_segs == cfg->n_bands && N % cfg->n_bands == 0 && cfg->decide != CRN_DECIDE_ANN) {
+    const int W = N / cfg->n_bands;
+    bool ok = W == 64 || W == 128 || W == 256;
+    for (int b = 0; ok && b < cfg->n_bands; b++)
+      ok = cfg->segs[b].band == b && cfg->segs[b].lo == b * W && cfg->segs[b].hi == (b + 1) * W;
+    if (ok) h->aligned_shift = W == 64 ? 6 : W == 128 ? 7 : 8;
   }
   seg_begin[cfg->n_bands] = (int)seg_lo.size();
   bins_begin[cfg->n_bands] = (int)bins.size();
@@ -287,9 +295,15 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
       reg_close = reg_close && (v == 2 || v == 13 || v == 16 || v == 17 || v == 18 || (v == 7 && rows_ok));
     }
     const bool pruned = plain4096 && reg_close && (h->variant == 0 || h->variant == 13) && (h->row_mask & ~0x8267u) == 0;
-    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%d,CLOSE=%s%s>",
+    // periodic Hann in energy mode: the window is folded into pass 1 (whole frames); with the Welch scan's plan
+    // (N = 4096, equal contiguous bands) the close forms band sums by DPP
+    const bool hann_fold = h->cfg.window == CRN_WINDOW_HANN && h->cfg.mode != CRN_MODE_REF_MAG;
+    const bool aligned = hann_fold && h->cfg.fft_len == 4096 && h->aligned_shift != 0;
+    if (hann_fold) tl = 1;
+    std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%s,CLOSE=%s%s>",
                   h->cfg.fft_len / 256, nbuf, pf, nt, tl, pk,
-                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window != CRN_WINDOW_RECT, reg_close ? "registers" : "lds",
+                  h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window == CRN_WINDOW_RECT ? "0" : hann_fold ? "hann-in-pass1" : "table",
+                  aligned ? "aligned-bands(dpp)" : reg_close ? "registers" : "lds",
                   pruned ? ",PASS3_ROWS=0x8267(reference channel plan; full rows when a spectrum is requested)" : "");
   }
   return CRN_OK;
@@ -359,6 +373,7 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.decide = c.decide;
   p.ref_band = c.ref_band;
   p.hann_sym = c.window == CRN_WINDOW_HANN;
+  p.aligned_shift = d_out->spectrum == nullptr ? h->aligned_shift : 0;
   p.row_mask = h->row_mask;
   p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;

@@ -43,6 +43,7 @@ struct SenseParams {
   int decide;
   int ref_band;
   int n_row_entries;       // > 0: band sums from registers (epoch_close); entries in band_tab
+  int aligned_shift;       // N = 4096 and the plan is n_bands equal contiguous bands of 2^aligned_shift bins (6..8), else 0
   int hann_sym;            // the window table is a periodic Hann: w[n + N/2] = 1 - w[n] (may be folded into pass 1)
   unsigned row_mask;       // N = 4096: bit d set when some band touches bins [256 d, 256 d + 256)
   // outputs (device, nullable)

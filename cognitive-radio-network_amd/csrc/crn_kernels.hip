@@ -386,6 +386,7 @@ enum : int {
   kRegBands = 8192, // epoch close forms the band sums from registers (plans with n_row_entries > 0, no spectrum)
   kHannSym = 16384, // periodic Hann folded into pass 1's first butterflies (w[n + N/2] = 1 - w[n]): 8 window registers
   kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
+  kAlignedBands = 65536, // N = 4096, equal contiguous bands of 64 / 128 / 256 bins (p.aligned_shift): band sums by DPP + one barrier
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -940,8 +941,64 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   const int lane = t % TEAM;
   lds_f32 *part = reinterpret_cast<lds_f32 *>(tab_off + kBandTabWords * 4);  // [256 / TEAM][16]
   [[maybe_unused]] const lds_f32 *feat = nullptr;
-  // Two forms of the close, chosen per launch (one kernel holding both spilled in the frame loop):
-  if constexpr ((C::OPT & kRegBands) != 0) {
+  // Three forms of the close, chosen per launch (one kernel holding several spilled in the frame loop):
+  if constexpr ((C::OPT & kAlignedBands) != 0) {
+    // Equal contiguous bands of W = 2^sh bins, sh = 6..8 (the Welch scan's 64 channels of 64 bins), N = 4096:
+    // thread (a, m_lo) holds bins 256 d + 16 m_lo + a in acc[d], so band (256 d + 16 m_lo) >> sh is the sum over
+    // all 16 a and over a group of G = W / 16 consecutive m_lo — lanes of one DPP row.  Group sums by DPP
+    // (no LDS), the four rows of a wave through the wave's OWN exchange rows (only x1 writes of other waves
+    // ever touch them, and those sit between the frame's two barriers), one barrier, then one lane per band adds
+    // the 16 values of a: 2-4 DPP adds per register, <= 16 narrow LDS writes and one barrier instead of a
+    // spectrum image, three barriers and a table walk (5 % of the Welch stream at K = 8).
+    static_assert(R3 == 16 && !MAG, "aligned-band close: N = 4096, energy mode");
+    const int sh = p.aligned_shift;   // uniform
+    const int G = 1 << (sh - 4), nb = p.n_bands, al = (tid >> 4) & 3, r = m_lo & (G - 1), grp_b = m_lo >> (sh - 4);
+    constexpr int kStride = 72;       // floats per a-row of partials: 72 mod 32 = 8 keeps a wave's rows on distinct banks
+    lds_f32 *mine = reinterpret_cast<lds_f32 *>(c.lds_base + (unsigned)(4 * c.wave * G::ROW * sizeof(cx))) + al * kStride;
+    const float thr_lane = thr[tid & 63];
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+      float v = acc[d];
+      acc[d] = 0.f;  // .cpp:287
+      v = dpp_add<0xB1>(v);
+      v = dpp_add<0x4E>(v);
+      if (sh >= 7) v = dpp_add<0x141>(v);
+      if (sh >= 8) v = dpp_add<0x140>(v);
+      if ((d & (G - 1)) == r) mine[(d << (8 - sh)) + grp_b] = v;   // one lane of the group stores the group's sum
+    }
+    if constexpr ((C::OPT & kTrace) != 0) tr1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if constexpr ((C::OPT & kTrace) != 0) tr2 = __builtin_amdgcn_s_memtime();
+    if (c.wave == 0) {
+      const int b = tid;  // one lane per band (n_bands <= 64)
+      float sum = 0.f;
+      if (b < nb) {
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) {
+          const lds_f32 *src = reinterpret_cast<const lds_f32 *>(c.lds_base + (unsigned)(4 * w4 * G::ROW * sizeof(cx)));
+          const float a0 = src[b], a1 = src[kStride + b], a2 = src[2 * kStride + b], a3 = src[3 * kStride + b];
+          sum += a0;
+          sum += a1;
+          sum += a2;
+          sum += a3;
+        }
+      }
+      if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
+      const float f = __fdiv_rn(sum, Kf);
+      const bool in = b < nb;
+      if (p.decide == CRN_DECIDE_THRESHOLD_K) {
+        const float ref = p.ref_band >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), p.ref_band)) : 1.0f;
+        const bool occ = active && in && f > thr_lane * ref;
+        if (active && in && p.occupancy != nullptr) p.occupancy[epoch * nb + b] = (uint8_t)occ;
+        const unsigned long long m = __ballot(occ);
+        if (active && b == 0 && p.decision != nullptr) p.decision[epoch] = __popcll(m);
+      } else if (active) {
+        if (b == 0 && p.decision != nullptr) p.decision[epoch] = 0;
+        if (in && p.occupancy != nullptr) p.occupancy[epoch * nb + b] = 0;
+      }
+      if (active && in && p.features != nullptr) p.features[epoch * nb + b] = f;
+    }
+  } else if constexpr ((C::OPT & kRegBands) != 0) {
     // Band sums straight from the accumulator registers: no LDS image of the spectrum, no barrier
     // before it (nothing aliases the exchange buffers) and none after the decision.  Thread bins are
     // base_j + 256 d; the host cut the band plan at the 256-bin rows (crn_api.cpp), so each entry is
@@ -1592,8 +1649,13 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
   // window registers fewer; the A/B numbers are in DESIGN.md §5)
-  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant))
+  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant)) {
+    if constexpr (R3 == 16) {  // the Welch scan's plan (equal contiguous bands): band sums without the spectrum image
+      if (p.aligned_shift != 0)
+        return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);
+    }
     return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
+  }
   if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || (win && variant != 17) || p.L != Geo<R3>::N)
     variant = kDefaultVariant;
   // The plain 4096-point kernel runs 4 workgroups per CU with the compressed pass-1 table and pass 2

@@ -453,6 +453,37 @@ def test_ingest_ring_many_streams(built):
     sensor.close()
 
 
+@pytest.mark.parametrize("n_bands,K,ref_band,n_epochs", [(64, 8, -1, 13), (32, 3, 5, 9), (16, 5, -1, 7), (64, 1, 0, 5)])
+def test_aligned_band_close_matches_oracle(built, n_bands, K, ref_band, n_epochs):
+    """N = 4096 Hann with equal contiguous bands of 64 / 128 / 256 bins (the Welch scan's plan) takes the
+    epoch close that forms band sums by DPP + one barrier; absolute and relative thresholds, short K, a ragged
+    batch; and the same handle with a spectrum request falls back to the LDS form — same features."""
+    cfg = cs.cfg_welch(4096, K, n_bands)
+    cfg.ref_band = ref_band
+    iq, _ = signals.make_epochs(cfg, n_epochs, seed=n_bands + K)
+    probe = orc.run(cfg, iq, n_epochs)["features"]
+    for b in range(n_bands):   # thresholds between the idle and the driven level, outside the margin band
+        cfg.thresh[b] = float(3.0 * np.median(probe[:, b])) if ref_band < 0 else 3.0
+    if ref_band >= 0:
+        cfg.thresh[ref_band] = float("inf")
+    s = cs.Sensor(cfg)
+    assert "CLOSE=" in s.kernel_info()["name"]
+    got = s.run_host(iq, n_epochs)
+    got_spec = s.run_host(iq, n_epochs, want_spectrum=True)
+    s.close()
+    want = orc.run(cfg, iq, n_epochs)
+    assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0)
+    assert np.allclose(got_spec["features"], want["features"], rtol=1e-5, atol=0)
+    ref = want["features"][:, ref_band:ref_band + 1] if ref_band >= 0 else 1.0
+    thr = np.array(cfg.thresh[:n_bands], np.float32)[None, :] * ref
+    safe = ~np.isfinite(thr) | (np.abs(want["features"] / np.where(np.isfinite(thr), thr, 1.0) - 1) > 1e-4)
+    assert np.array_equal(got["occupancy"][safe], want["occupancy"][safe])
+    assert np.array_equal(got_spec["occupancy"][safe], want["occupancy"][safe])
+    if safe.all():
+        assert np.array_equal(got["decision"], want["decision"])
+    assert got["occupancy"].any()
+
+
 def test_ingest_ring_never_blocks_and_handles_uneven_streams(built):
     """push() refuses a packet (CRN_ERR_BUSY) instead of waiting when both batch buffers are on the GPU;
     streams that advance at different rates leave open epochs behind a launch, which move on to the other
