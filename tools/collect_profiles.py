@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the round's evidence from gpurun_out/r01 (scratch) into profiles/ (tracked) and derive
+"""Copy the round's evidence from gpurun_out/<tag> (scratch) into profiles/ (tracked) and derive
 profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(R, "gpurun_out", "r01")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(R, "gpurun_out", tag)
 DST = os.path.join(R, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(DST, exist_ok=True)
 for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("bench_headline.json", f"{tag}_bench_headline.json"),
                  ("bench_cfg1_1024.json", f"{tag}_bench_cfg1_1024pt.json"), ("bench_cfg3_ref512.json", f"{tag}_bench_cfg3_ref512.json"),
@@ -13,7 +13,12 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("bench_unpruned.json", f"{tag}_bench_headline_unpruned.json"), ("bench_noclose.json", f"{tag}_bench_ablation_no_epoch_close.json"),
                  ("bench_e512.json", f"{tag}_bench_energy_512pt.json"), ("bench_e2048.json", f"{tag}_bench_energy_2048pt.json"),
                  ("membw_policy.txt", f"{tag}_stream_ceiling_policy.txt"), ("cfg3_decisions.txt", f"{tag}_cfg3_decisions_1M_epochs.txt"),
-                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("smoke.log", f"{tag}_smoke.log")):
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("smoke.log", f"{tag}_smoke.log"),
+                 ("bench_cfg2_welch_K32.json", f"{tag}_bench_cfg2_welch_K32.json"), ("bench_cfg4_scan_1rank.json", f"{tag}_bench_cfg4_scan_one_rank_rccl.json"),
+                 ("engine_rate.txt", f"{tag}_engine_rate.txt"), ("zeros_probe.txt", f"{tag}_zero_input_probe.txt"),
+                 ("power_probe.txt", f"{tag}_power_clock_probe.txt"), ("cpu_scaling.txt", f"{tag}_cpu_thread_scaling.txt"),
+                 ("per_bin_error_at_floor.txt", f"{tag}_per_bin_error_at_floor.txt"),
+                 ("engine_execute_latency.txt", f"{tag}_engine_execute_latency.txt")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
         shutil.copy(m[-1], os.path.join(DST, dst))
@@ -33,10 +38,10 @@ def mean_counter(sub, name):
 HOW = ("rocprofv3 --pmc FETCH_SIZE [GRBM_GUI_ACTIVE] and --pmc WRITE_SIZE [TCC_HIT_sum TCC_MISS_sum] in separate passes "
        "(--kernel-trace only) over `python3 bench.py --steps 5 --warmup 20 --cpu-epochs 0 <workload flags>`; FETCH_SIZE is KiB and on "
        "gfx950 tallies each 128-B request as 64 B, so x2 (MI355X_MICROARCH.md, HBM section); the x2 was re-calibrated for "
-       "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt)")
+       "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt (round 1; the load instruction is unchanged))")
 out = {"_how": HOW}
 # key = bench.py's f"{mode}{N}"; the unpruned 4096-pt kernel is recorded for the record only
-for key, sub, bench in (("energy4096", "", "bench_headline.json"), ("energy1024", "_cfg1", "bench_cfg1_1024.json"),
+for key, sub, bench in (("energy4096", "_headline", "bench_headline.json"), ("energy1024", "_cfg1", "bench_cfg1_1024.json"),
                         ("ref512", "_cfg3", "bench_cfg3_ref512.json"), ("welch4096", "_cfg2", "bench_cfg2_welch.json"),
                         ("energy512", "_e512", "bench_e512.json"), ("energy2048", "_e2048", "bench_e2048.json"),
                         ("energy4096_unpruned", "_unpruned", "bench_unpruned.json")):
@@ -54,4 +59,11 @@ for key, sub, bench in (("energy4096", "", "bench_headline.json"), ("energy1024"
     print(key, out[key])
 if len(out) > 1:
     json.dump(out, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
+subprocess.run([sys.executable, os.path.join(R, "tools", "collect_valu_counters.py"), tag,
+                f"energy4096=pmc_{tag}_headline:", f"welch4096=pmc_{tag}_welch:--mode welch", f"energy2048=pmc_{tag}_e2048:--fft 2048",
+                f"ref512=pmc_{tag}_ref:--mode ref", f"energy1024=pmc_{tag}_e1024:--fft 1024"])
+for name in ("headline", "welch", "e2048", "ref", "e1024"):
+    src = os.path.join(SRC, f"pmc_sq_{name}.txt")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(DST, f"{tag}_pmc_sq_{name}.txt"))
 print(sorted(os.listdir(DST)))

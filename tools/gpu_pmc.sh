@@ -2,7 +2,7 @@
 # PMC passes over the bench (variant $V), one counter group per run (no trace domains mixed in).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V=${V:-3}
+V=${V:-0}
 EXTRA=${EXTRA:-}
 TAG=${TAG:-v$V}
 OUT=$R/gpurun_out/pmc_$TAG
