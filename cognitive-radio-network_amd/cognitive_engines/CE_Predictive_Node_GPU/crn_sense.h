@@ -203,7 +203,10 @@ CRN_API int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t wa
  * K-packet epochs — each packet is copied once, straight into its place in a pinned batch buffer —
  * ships batches to the GPU asynchronously on a private stream (H2D -> kernel -> D2H, two buffers)
  * and hands decisions back through a non-blocking poll.  crn_ingest_push and crn_ingest_poll never
- * wait for the GPU and never allocate: `execute()` only copies one packet and checks an event. */
+ * wait for the GPU and never allocate: `execute()` only copies one packet and checks an event.
+ * The ring owns a launcher thread that makes every HIP call (it calls crn_sense_run_device on the
+ * handle: do not use crn_sense_run_host / crn_sense_reserve_host on that handle from another
+ * thread while batches are in flight; crn_sense_run_device is safe to call concurrently). */
 typedef struct crn_ingest crn_ingest;
 
 typedef struct crn_epoch_result {
