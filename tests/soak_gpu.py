@@ -25,7 +25,19 @@ for seed in range(n_seeds):
         for b in range(nb):
             cfg.segs[b].lo, cfg.segs[b].hi, cfg.segs[b].band = int(edges[2 * b]), int(edges[2 * b + 1]), b
             cfg.thresh[b] = 1e-3
+    aligned = rng.random() < 0.15   # the Welch scan's plan: equal contiguous bands (N = 4096 takes the DPP band-sum close)
+    if aligned:
+        nb = int(rng.choice([16, 32, 64]))
+        cfg.n_bands, cfg.n_segs, cfg.ref_band = nb, nb, int(rng.choice([-1, -1, 3]))
+        for b in range(nb):
+            cfg.segs[b].lo, cfg.segs[b].hi, cfg.segs[b].band = b * (n // nb), (b + 1) * (n // nb), b
+            cfg.thresh[b] = 1e-3 if cfg.ref_band < 0 else 1.0
+        cfg.decide = int(rng.choice([1, 1, 2]))
+        if rng.random() < 0.7:
+            cfg.window, cfg.mode, L = 1, 1, n
     variant = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 8, 9, 10])) if n == 4096 else 0
+    if cfg.window == 1 and cfg.mode == 1 and L == n and rng.random() < 0.5:
+        variant = int(rng.choice([19, 20, 21, 22]))   # A/B set of the windowed kernel
     want_spec = bool(rng.random() < 0.5)
     n_epochs = int(rng.integers(1, 40))
     # Welch (hop N/2, windowed, whole frames) for a fifth of the windowed cases
@@ -51,6 +63,11 @@ for seed in range(n_seeds):
     s.close()
     want = orc.run(cfg, iq, n_epochs, L=L, want_spectrum=want_spec, epoch_stride=stride)
     ok = np.allclose(got["features"], want["features"], rtol=3e-5, atol=0)
+    if aligned and cfg.decide == 1:   # occupancy away from the threshold must agree
+        ref_f = want["features"][:, cfg.ref_band:cfg.ref_band + 1] if cfg.ref_band >= 0 else 1.0
+        thr = np.array(cfg.thresh[:cfg.n_bands], np.float32)[None, :] * ref_f
+        safe = np.abs(want["features"] / thr - 1) > 1e-4
+        ok = ok and np.array_equal(got["occupancy"][safe], want["occupancy"][safe])
     if want_spec:
         truth = signals.spectrum_f64(cfg, iq, n_epochs, L=L) if stride == 0 else None
         if truth is None:
@@ -62,6 +79,6 @@ for seed in range(n_seeds):
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, dict(n=n, mode=cfg.mode, K=cfg.frames_per_epoch, win=cfg.window, L=L, variant=variant,
-                                         spec=want_spec, epochs=n_epochs, ref_plan=ref_plan, welch=welch, epw=epw, tail=tail, stride=stride))
+                                         spec=want_spec, epochs=n_epochs, ref_plan=ref_plan, welch=welch, aligned=aligned, nb=cfg.n_bands, decide=cfg.decide, epw=epw, tail=tail, stride=stride))
 print(f"soak: {n_seeds} configurations, {bad} mismatches")
 sys.exit(1 if bad else 0)
