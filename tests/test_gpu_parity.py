@@ -356,6 +356,41 @@ def test_engine_with_wall_clock_gate_never_stalls_the_ce_thread(built, tmp_path)
             + " ".join(st) + "\n" + " ".join(cl) + "\nsensing re-arm gaps (s): " + " ".join(f"{g:.4f}" for g in gaps) + "\n")
 
 
+def test_engine_between_the_ecr_worker_threads(built, tmp_path):
+    """Rows a14 / a15 as they run in a CRTS node: tests/harness/ecr_threads plays the rx worker and the CE worker
+    as two THREADS with the reference's own locking (src/extensible_cognitive_radio.cpp:1299-1324, 1775-1803:
+    CE_mutex held across execute(), cond_signal hand-off, ce_timeout_ms = 0 so the CE thread spins and signals
+    are lost whenever it is not inside timedwait).  The "radio" delivers packets at the real rate (364 samples /
+    13 Msps = 28 us) from a capture whose driven channel changes every 0.25 s.  The engine runs with its default
+    arguments.  Whatever frames get through, every epoch whose ten frames came from one segment must decide
+    that segment's channel; execute() must stay far below a packet time; and the rx thread's wait for CE_mutex —
+    what the engine costs the radio — is printed."""
+    import os
+    cfg = cs.cfg_reference()
+    L, per_seg = 364, 64
+    segs = []
+    for ch in range(4):
+        iq, _ = signals.make_epochs(cfg, 7, seed=900 + ch, L=L, picks=[ch] * 7)
+        segs.append(iq[: per_seg * L * 2])
+    cap = np.concatenate(segs)
+    out = _run_harness("ecr_threads", ["IQ", str(L), str(per_seg), "1.6", "-v", "0"], tmp_path, cap)
+    dec = [ln.split() for ln in out if ln.startswith("decision ")]
+    assert len(dec) >= 8, out[-6:]
+    pure = [(int(w[1]), int(w[3])) for w in dec if w[5] == "1"]
+    assert len(pure) >= 6 and all(d == seg for d, seg in pure), pure
+    assert len({seg for _, seg in pure}) >= 3          # several channels were seen
+    ex = [ln for ln in out if ln.startswith("execute_us")][0].split()
+    stat = {ex[i]: float(ex[i + 1]) for i in range(1, len(ex), 2)}
+    assert stat["median"] < 5.0 and stat["p99"] < 28.0, stat
+    tail = [ln for ln in out if ln.startswith(("packets", "rx_wait", "execute_us"))]
+    print("\n".join(tail))
+    out_dir = os.environ.get("CRN_EVIDENCE_DIR")
+    if out_dir:
+        open(os.path.join(out_dir, "engine_between_ecr_threads.txt"), "w").write(
+            "tests/harness/ecr_threads: rx worker + CE worker as threads with the reference's locking, packets at 28 us, "
+            "engine with default arguments, 1.6 s\n" + "\n".join([" ".join(w) for w in dec] + tail) + "\n")
+
+
 def test_full_size_batch_properties(built):
     """BASELINE-size batch (7168 epochs x 10 x 4096-pt = 2.2 GiB, resident in HBM), checked through
     size-independent properties instead of the oracle:
