@@ -6,8 +6,11 @@
  *   this path, and it cannot be built in this image: CE_Predictive_Node.hpp:4 includes
  *   <liquid/liquid.h> and extensible_cognitive_radio.hpp:9-11 includes UHD headers; liquid-dsp,
  *   UHD and libconfig are neither vendored nor installed, and writing stand-ins for them is not
- *   allowed.  So this restatement is checked only against the DFT definition in float64 and
- *   against hand-derived known answers (tests/golden/), never against reference output.
+ *   allowed.  So this restatement is never checked against reference output.  What it IS checked
+ *   against (tests/test_golden.py, tests/test_oracle.py): fixtures written by an independent float64
+ *   numpy statement of the same mathematics that shares no code with this file (tests/ref_f64.py ->
+ *   tests/golden/), SURVEY.md Appendix C's probe values, the DFT definition in float64, and
+ *   hand-derived known answers.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
  * shared object.  The product (libcrnsense) never links or calls it.
