@@ -72,6 +72,47 @@ def usable_cores():
     return n, why
 
 
+def live_traffic(args, epochs):
+    """(bytes per launch, how) from rocprofv3 --pmc passes over a short child run of the same workload, or (None, None).
+    FETCH_SIZE is in KiB and on gfx950 tallies each 128-B request as 64 B (x2: MI355X_MICROARCH.md, HBM section;
+    re-calibrated for this kernel's 8-byte loads in profiles/r01_fetch_size_calibration.txt); WRITE_SIZE reads true."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    tmp = tempfile.mkdtemp(prefix="crn_pmc_", dir="/tmp")
+    child = ["python3", os.path.abspath(__file__), "--steps", "5", "--warmup", "20", "--cpu-epochs", "0", "--no-alt",
+             "--no-live-traffic", "--fft", str(args.fft), "--mode", args.mode, "--variant", str(args.variant),
+             "--epochs", str(epochs)]
+    if args.frames > 0:
+        child += ["--frames", str(args.frames)]
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=180)
+            if r.returncode != 0:
+                return None, None
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            vals = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
+                    if "sense_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not vals:
+                return None, None
+            got[ctr] = sum(vals[-5:]) / len(vals[-5:])   # the timed launches
+    except Exception:
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = int(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a "
+                   "5-step child run of this workload; FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +134,9 @@ def main():
                          "of the kernel time is the clock the chip holds under load (implies --no-check, no CPU baseline)")
     ap.add_argument("--force-collective", action="store_true",
                     help="dry run of the N>1 code path on one GPU: RCCL group of one rank, all-gather every step")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 counter passes of a short child run (N = 1 only); "
+                         "use the committed figure instead")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "r02_valu_counters.json"))
     args = ap.parse_args()
@@ -280,10 +324,18 @@ def main():
             return None
 
     mode_key = f"{'welch' if args.mode == 'scan' else args.mode}{N}"
-    traffic = None
-    tj = committed(args.traffic_json, mode_key)
-    if tj:  # measured once per kernel with rocprofv3 PMC passes of this command; scales linearly with the batch
-        traffic = int(tj["hbm_bytes_per_launch"] * (E / tj["epochs"]))
+    traffic, traffic_source = None, None
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ   # already under a profiler
+    if rank == 0 and world == 1 and not multi and not args.no_live_traffic and not args.zeros and not profiled:
+        # HBM bytes per launch, measured now: two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a
+        # pass on gfx950) over a short child run of this same workload — a child process, started while this one idles.
+        traffic, traffic_source = live_traffic(args, E)
+    if traffic is None:
+        tj = committed(args.traffic_json, mode_key)
+        if tj:  # measured once per kernel with rocprofv3 PMC passes of this command; scales linearly with the batch
+            traffic = int(tj["hbm_bytes_per_launch"] * (E / tj["epochs"]))
+            traffic_source = (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this "
+                              "command (committed), scaled by the batch")
 
     # ---- second roofline for the windowed kernels: VALU ---------------------------------------------
     roofline_valu = None
@@ -408,9 +460,7 @@ def main():
                        "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy (crn_comm_*, side stream)" if multi else ""),
                        "alt": alt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of "
-                                            "this command, scaled by the batch") if traffic else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_mean": kern_ms_mean, "kernel_ms_min": float(np.min(kern_ms)),
                          "kernel_ms_median": float(np.median(kern_ms)), "kernel_ms_max": float(np.max(kern_ms)),
                          "events": "span" if args.span_events else "per-launch"},

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 def _run(*extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                          "--epochs", "512", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                          "--epochs", "512", *(() if "--live" in extra else ("--no-live-traffic",)),
+                          *[e for e in extra if e != "--live"]], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout            # exactly one line, whatever the libraries print
@@ -36,6 +37,18 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
     assert r["events"] == "per-launch" and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"]
     assert d["metric"].startswith("Msamples/s IQ through FFT+energy-detect, 4096-pt x 3ch")
     assert d["config"]["workload"].startswith("4096-pt")
+
+
+def test_bench_measures_hbm_traffic_in_the_run(built):
+    """roofline.traffic comes from rocprofv3 counter passes of a short child run of the same workload (FETCH_SIZE x 2 +
+    WRITE_SIZE), not from a committed file: within 1 % of the algorithmic bytes for the read-once kernel."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    d = _run("--cpu-epochs", "0", "--live")
+    r = d["roofline"]
+    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+    assert abs(r["traffic"] / d["config"]["bytes_per_gpu_per_step"] - 1) < 0.01, r
 
 
 @pytest.mark.parametrize("mode", [[], ["--mode", "ref"], ["--mode", "welch"], ["--mode", "scan"]])

@@ -2,7 +2,7 @@
 # Where the 1400 W go: package power and sclk for the ablation variants of the 4096-point kernel
 # (11 stream only, 14 butterflies only, 15 butterflies + LDS exchanges without reload, 16 no epoch close, 0 default).
 probe() {
-  python bench.py --cpu-epochs 0 --no-alt --no-check --steps 3000 --warmup 50 $2 > /tmp/b.json 2>/dev/null &
+  python bench.py --cpu-epochs 0 --no-live-traffic --no-alt --no-check --steps 3000 --warmup 50 $2 > /tmp/b.json 2>/dev/null &
   pid=$!
   sleep 3.5
   for i in 1 2 3; do

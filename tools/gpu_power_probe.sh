@@ -1,7 +1,7 @@
 #!/bin/bash
 # Board power and clocks while a kernel runs back to back (rocm-smi polled from a second process).
 probe() {  # label, bench args
-  python bench.py --cpu-epochs 0 --no-alt --steps 4000 --warmup 50 $2 > /tmp/b.json 2>/dev/null &
+  python bench.py --cpu-epochs 0 --no-live-traffic --no-alt --steps 4000 --warmup 50 $2 > /tmp/b.json 2>/dev/null &
   pid=$!
   sleep 4
   for i in 1 2 3 4 5; do

@@ -2,7 +2,7 @@
 # A/B of the windowed-kernel variants on one box (boxes differ by a few %: only numbers of one call compare).
 for rep in 1 2; do
 for v in ${VARIANTS:-22 19 20 21 0}; do
-  python bench.py --mode welch --cpu-epochs 0 --variant $v ${EXTRA:-} 2>/tmp/err_$v | python -c "
+  python bench.py --mode welch --cpu-epochs 0 --no-live-traffic --variant $v ${EXTRA:-} 2>/tmp/err_$v | python -c "
 import sys, json
 t = sys.stdin.read().strip()
 if not t:
