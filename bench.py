@@ -72,17 +72,16 @@ def usable_cores():
     return n, why
 
 
-def live_traffic(args, epochs):
-    """(bytes per launch, how) from rocprofv3 --pmc passes over a short child run of the same workload, or (None, None).
-    FETCH_SIZE is in KiB and on gfx950 tallies each 128-B request as 64 B (x2: MI355X_MICROARCH.md, HBM section;
-    re-calibrated for this kernel's 8-byte loads in profiles/r01_fetch_size_calibration.txt); WRITE_SIZE reads true."""
+def live_counters(args, epochs, passes):
+    """rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over a short child run of the same workload:
+    {counter: mean over the timed launches, "kernel_s": mean kernel duration of the last pass}, or None."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, None
+        return None
     tmp = tempfile.mkdtemp(prefix="crn_pmc_", dir="/tmp")
     child = ["python3", os.path.abspath(__file__), "--steps", "5", "--warmup", "20", "--cpu-epochs", "0", "--no-alt",
              "--no-live-traffic", "--fft", str(args.fft), "--mode", args.mode, "--variant", str(args.variant),
@@ -91,23 +90,41 @@ def live_traffic(args, epochs):
         child += ["--frames", str(args.frames)]
     got = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
+        for i, group in enumerate(passes):
+            out = os.path.join(tmp, str(i))
+            r = subprocess.run(["rocprofv3", "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
                                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=180)
             if r.returncode != 0:
-                return None, None
-            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
-            vals = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
-                    if "sense_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
-            if not vals:
-                return None, None
-            got[ctr] = sum(vals[-5:]) / len(vals[-5:])   # the timed launches
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "sense_kernel" in row["Kernel_Name"]:
+                        per.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for ctr in group:
+                if ctr not in per:
+                    return None
+                got[ctr] = sum(per[ctr][-5:]) / len(per[ctr][-5:])   # the timed launches
+            dur = [(int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+                   for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True)
+                   for row in csv.DictReader(open(f)) if "sense_kernel" in row["Kernel_Name"]][-5:]
+            if dur:
+                got["kernel_s"] = sum(dur) / len(dur)
     except Exception:
-        return None, None
+        return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return got
+
+
+def live_traffic(args, epochs):
+    """(bytes per launch, how) from FETCH_SIZE and WRITE_SIZE passes (they cannot share a pass on gfx950), or (None, None).
+    FETCH_SIZE is in KiB and on gfx950 tallies each 128-B request as 64 B (x2: MI355X_MICROARCH.md, HBM section;
+    re-calibrated for this kernel's 8-byte loads in profiles/r01_fetch_size_calibration.txt); WRITE_SIZE reads true."""
+    got = live_counters(args, epochs, [["FETCH_SIZE"], ["WRITE_SIZE"]])
+    if not got:
+        return None, None
     total = int(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
     return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a "
                    "5-step child run of this workload; FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024")
@@ -349,11 +366,22 @@ def main():
                          "note": "algorithmic flops (5 N log2 N + 6 N per frame; every hop of N/2 new samples costs a whole "
                                  "N-point transform) against the fp32 vector peak at 2.4 GHz; butterflies are add-heavy, "
                                  "so issue slots, not flops, are what runs out: see issue_frac"}
-        vj = committed(args.valu_json, mode_key)
-        if vj:
-            roofline_valu.update({"issue_frac": vj["valu_busy_frac"], "clock_ghz": vj["clock_ghz"],
-                                  "valu_insts_per_wave_frame": vj["valu_insts_per_wave_frame"],
-                                  "issue_frac_source": vj["source"]})
+        lv = None
+        if rank == 0 and world == 1 and not multi and not args.no_live_traffic and not args.zeros and not profiled:
+            lv = live_counters(args, E, [["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]])
+        if lv and "kernel_s" in lv:
+            cycles = lv["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+            roofline_valu.update({"issue_frac": lv["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),   # quad-cycles, 1024 SIMDs
+                                  "clock_ghz": cycles / lv["kernel_s"] / 1e9,
+                                  "valu_insts_per_wave_frame": lv["SQ_INSTS_VALU"] / (frames * (N // 16) / 64.0),
+                                  "issue_frac_source": "measured in this run: rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU "
+                                                       "GRBM_GUI_ACTIVE over a 5-step child run; clock = GRBM_GUI_ACTIVE / 8 / kernel time"})
+        else:
+            vj = committed(args.valu_json, mode_key)
+            if vj:
+                roofline_valu.update({"issue_frac": vj["valu_busy_frac"], "clock_ghz": vj["clock_ghz"],
+                                      "valu_insts_per_wave_frame": vj["valu_insts_per_wave_frame"],
+                                      "issue_frac_source": vj["source"] + " (committed)"})
 
     # ---- config.alt: the same metric on SURVEY.md §8(d)'s 2 GiB batch, and without row pruning -------
     alt = None
