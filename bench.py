@@ -191,8 +191,10 @@ def main():
         label = "512-pt x 3ch reference-exact + ANN"
     elif args.mode in ("welch", "scan"):
         cfg = cs.cfg_welch(args.fft, 8, 64)
+        # per-band threshold = lambda x the noise-floor estimate (lambda = 4): a band of N/64 bins of
+        # Hann-windowed noise of power 1e-6 holds (N/64) x N x 1e-6 x mean(w^2), mean(w^2) = 3/8
         for b in range(64):
-            cfg.thresh[b] = 1e-2
+            cfg.thresh[b] = 4.0 * (args.fft / 64) * args.fft * 1e-6 * 0.375
         workload = f"cfg2: {args.fft}-pt Welch PSD (Hann, 50% overlap) x 64 bands + threshold"
         label = f"{args.fft}-pt Welch x 64ch"
         if args.mode == "scan":
@@ -312,6 +314,13 @@ def main():
         mism = int((occ_host != want).any(axis=1).sum())
         if mism:
             raise SystemExit(f"bench: {mism} epochs whose occupancy differs from the driven pattern")
+    elif cfg.decide == cs.DECIDE_THRESHOLD:
+        # Welch / scan: the driven channel must read occupied in every epoch (others may too: an epoch's last frame
+        # reaches half a frame into the next epoch's traffic, and a tone cut off mid-frame splatters)
+        idx = np.nonzero(picked > 0)[0]
+        mism = int((occ_host[idx, picked[idx] - 1] != 1).sum())
+        if mism:
+            raise SystemExit(f"bench: {mism} epochs whose driven channel does not read occupied")
     elif cfg.decide == cs.DECIDE_ANN:
         mism = int((dec.cpu().numpy() != picked).sum())
         if mism:

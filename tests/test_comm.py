@@ -61,3 +61,22 @@ def test_one_rank_communicator_end_to_end(built):
         comm.local(-1, stream)
     sensor.close()
     comm.close()
+
+
+@pytest.mark.gpu
+def test_scan_node_cpp_program_over_the_c_abi(built, tmp_path):
+    """BASELINE.json configs[4] as a C++ host program that uses nothing but include/crn_sense.h (tests/harness/scan_node.cpp):
+    streams of 64 Welch channels generated on the device (Markov primary user), sensed, occupancy gathered over RCCL through
+    crn_comm_* — here as a world of one rank (the pool hands out one GPU).  Exit code 0 = own block in place in the gathered
+    vector and exactly the driven channel occupied in every epoch."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", "scan_node")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([exe, "4", "256", "10", str(tmp_path / "rccl_id")], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank 0/1")][0]
+    assert "own block in place: yes" in line and "driven channel flagged in 1024 of 1024 epochs" in line
+    occupied = float(line.split(" epochs, ")[-1].split()[0])
+    assert 1.0 <= occupied < 8.0       # the driven channel, plus splatter where the traffic changes inside a frame
+    print(line)
