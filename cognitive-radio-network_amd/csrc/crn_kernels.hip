@@ -1630,6 +1630,7 @@ static constexpr VariantDesc kVariants[] = {
     /* 20 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: 19 + pass-2 twiddles read from LDS ahead of their use
     /* 21 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: early pass-2 twiddle reads alone
     /* 22 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the plain form (16 window registers, twiddles read where used)
+    /* 23 */ {1, 1, 1, 0, 3, 0, 1},  // the default's work at 3 workgroups/CU with all twiddles in registers (fewer instructions, less LDS)
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -1708,6 +1709,10 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 17: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kTrace>(p, mag, win, stream);
       case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
+      case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
+        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+          return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kPrioValu | kMulti>(p, mag, win, stream);
     }
   }
   return hipErrorInvalidValue;
