@@ -168,7 +168,7 @@ def main():
     import torch.distributed as dist
 
     import crnsense as cs
-    from sharding import DeviceOccupancyExchange, shard
+    from sharding import make_device_exchange, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -243,7 +243,7 @@ def main():
             "occupancy": occ.data_ptr(), "spectrum": 0}
     # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the
     # all-gather of step i (side stream) overlaps the sensing kernel of step i + 1
-    ex = DeviceOccupancyExchange(E, cfg.n_bands, local_rank, rank, world) if multi else None
+    ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world) if multi else (None, "")
     n_done = 0
 
     def step(sn, epochs, out_ptrs, ev=None):
@@ -494,7 +494,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
                        "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
-                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of occupancy (crn_comm_*, side stream)" if multi else ""),
+                       "parallelism": f"stream-sharded x{world}" + (", " + ex_kind if multi else ""),
                        "alt": alt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
