@@ -177,6 +177,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcrnsense has no CPU path")
+    if local_rank >= torch.cuda.device_count():   # a launcher that shows each rank only its own GPU
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_collective
