@@ -317,6 +317,21 @@ def test_engine_drop_in_matches_reference_epoch(built, binary, mode, tmp_path):
     assert calls.startswith("calls stop_tx(0) set_rx_freq(8.33e+08) set_rx_rate(1.3e+07) stop_tx(0) set_ce_sensing(1)")
 
 
+def test_engine_truncates_packets_longer_than_the_fft(built, tmp_path):
+    """The reference copies ce_usrp_rx_buffer_length samples into its 512-sample FFT buffer unchecked
+    (CE_Predictive_Node.cpp:149) and overruns it when the UHD packet is longer; the drop-in engine takes the first
+    512 samples of such a packet.  Packets of 600 samples: decisions = the oracle's on the first 512 of each."""
+    cfg = cs.cfg_reference()
+    n_epochs, L = 6, 600
+    iq512, picks = signals.make_epochs(cfg, n_epochs, seed=61, L=512)
+    pk = iq512.reshape(n_epochs * 10, 512 * 2)
+    junk = np.random.default_rng(5).normal(0, 0.5, (n_epochs * 10, (L - 512) * 2)).astype(np.float32)   # loud: must not leak in
+    out = _run_harness("engine_harness", ["IQ", str(L), "-g", "0", "-v", "0"], tmp_path, np.concatenate([pk, junk], axis=1).ravel())
+    lines = [ln.split() for ln in out if ln.startswith("epoch ")]
+    assert len(lines) == n_epochs
+    _check_epoch_lines(lines, iq512, picks, 512)
+
+
 def test_engine_with_wall_clock_gate_never_stalls_the_ce_thread(built, tmp_path):
     """Row a11 (CE_Predictive_Node.cpp:127-141) with the engine exactly as a CRTS node would run it: default
     arguments (wall-clock gate ON, enqueue-only), rx worker forwarding packets only while sensing is on, CE

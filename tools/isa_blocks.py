@@ -15,6 +15,8 @@ for l in lines[start + 1:end]:
             blocks.append((name, cur)); cur, name = [], s.split(":")[0]
         continue
     cur.append(s.split()[0])
+    if s.startswith(("s_cbranch", "s_branch")):   # a branch ends the basic block even without a label after it
+        blocks.append((name, cur)); cur, name = [], name + "+"
 blocks.append((name, cur))
 def cls(op):
     if op.startswith("v_pk_add"): return "pk_add"
