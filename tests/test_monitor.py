@@ -63,3 +63,33 @@ def test_spectrum_monitor_tool_matches_float64(built, tmp_path, kind, fft, frame
     col = fft // 2 - 200
     assert got["average_db"][n_rows // 2 - 1, col] < got["average_db"][-1, col] - 10
     assert "peak bin of last averaged row" in r.stdout
+
+
+def test_monitor_and_reserve_argument_errors(built):
+    import ctypes as C
+    import torch
+    sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd")]
+    import crnsense as cs
+    dev = torch.device("cuda", 0)
+    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    cfg.window, cfg.decide = cs.WINDOW_BLACKMAN_HARRIS, cs.DECIDE_NONE
+    s = cs.Sensor(cfg)
+    spec = torch.zeros(4, 1024, dtype=torch.float32, device=dev)
+    state = torch.zeros(1024, dtype=torch.float32, device=dev)
+    for bad in (dict(kind=7), dict(alpha=0.0), dict(alpha=1.5), dict(n_rows=-1)):
+        kw = dict(n_rows=4, kind=cs.MONITOR_GNURADIO, alpha=0.1)
+        kw.update(bad)
+        with pytest.raises(cs.CrnError):
+            s.monitor_rows_device(spec.data_ptr(), kw["n_rows"], kw["kind"], kw["alpha"], True, state.data_ptr())
+    with pytest.raises(cs.CrnError):
+        s.monitor_rows_device(spec.data_ptr(), 4, cs.MONITOR_PSD, 0.1, True, 0)      # no state buffer
+    s.monitor_rows_device(spec.data_ptr(), 0, cs.MONITOR_PSD, 0.1, True, state.data_ptr())   # zero rows: nothing to do
+    with pytest.raises(cs.CrnError):
+        s.reserve_host(0)
+    s.reserve_host(3, want_spectrum=True)
+    ring = cs.Ingest(s, 1, 100, 1)
+    with pytest.raises(cs.CrnError):
+        ring.set_packet_len(101)       # longer than the ring was sized for
+    ring.set_packet_len(64)
+    ring.close()
+    s.close()
