@@ -602,6 +602,42 @@ def test_ingest_ring_never_blocks_and_handles_uneven_streams(built):
     sensor.close()
 
 
+def test_ingest_flush_launches_a_partial_batch_and_keeps_open_epochs(built):
+    """crn_ingest_flush: complete epochs go to the GPU although the batch is not full; an epoch that is still being staged
+    stays in the ring (its packets move to the other buffer) and completes later with nothing lost."""
+    import time
+    cfg = cs.cfg_reference()
+    L, K = 364, 10
+    sensor = cs.Sensor(cfg)
+    ring = cs.Ingest(sensor, 2, L, 8)                      # 8 epochs per batch: never reached here
+    data = []
+    for st in range(2):
+        iq, picks = signals.make_epochs(cfg, 2, seed=40 + st, L=L)
+        data.append((iq.reshape(2 * K, L * 2), picks))
+    for pkt in range(K):                                   # stream 0: one whole epoch
+        ring.push(0, np.ascontiguousarray(data[0][0][pkt]))
+    for pkt in range(4):                                   # stream 1: 4 of 10 packets
+        ring.push(1, np.ascontiguousarray(data[1][0][pkt]))
+    assert ring.poll() == []
+    ring.flush()
+    got = []
+    t0 = time.time()
+    while not got and time.time() - t0 < 5:
+        got += ring.poll()
+    assert [(r.stream, r.epoch_seq) for r in got] == [(0, 0)]
+    for pkt in range(4, K):                                # stream 1 finishes its epoch after the flush
+        ring.push(1, np.ascontiguousarray(data[1][0][pkt]))
+    ring.drain()
+    got += ring.poll()
+    assert [(r.stream, r.epoch_seq) for r in got] == [(0, 0), (1, 0)]
+    for r in got:
+        ref = orc.ref_epoch(data[r.stream][0][:K].ravel(), L)
+        assert r.decision == ref["decision"] == data[r.stream][1][0]
+        assert np.allclose(np.array(r.features[:4]), ref["features"], rtol=1e-5)
+    ring.close()
+    sensor.close()
+
+
 @pytest.mark.parametrize("n", [512, 4096])
 @pytest.mark.parametrize("K", [1, 2, 3, 7])
 def test_frames_per_epoch_edge_cases(built, n, K):
