@@ -190,7 +190,9 @@ void launcher_main(crn_ingest *g) {
       inflight.pop_front();
       continue;
     }
-    if (g->work.empty()) g->cv_work.wait_for(lk, std::chrono::microseconds(20));  // new work wakes it early
+    // new work wakes it early.  (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer models;
+    // wait_for would be pthread_cond_clockwait, which gcc 11's libtsan does not intercept: tests/harness/ring_unit.cpp)
+    if (g->work.empty()) g->cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(20));
   }
 }
 

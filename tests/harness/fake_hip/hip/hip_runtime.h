@@ -1,0 +1,47 @@
+// TEST INFRASTRUCTURE: a host-only stand-in for the handful of HIP runtime calls csrc/crn_ingest.cpp makes, so that
+// the ring's HOST logic (slot hand-out, single copy, hand-off to the launcher thread, BUSY refusals, flush / drain,
+// result order) can be unit-tested — under ThreadSanitizer — on a machine without a GPU (tests/harness/ring_unit.cpp).
+// "Device" memory is host memory, copies are memcpy, an event becomes ready g_fake_gpu_latency_ns after it is recorded.
+// Nothing of this is ever linked into the product.
+#ifndef CRN_FAKE_HIP_RUNTIME_H
+#define CRN_FAKE_HIP_RUNTIME_H
+#include <atomic>
+#include <chrono>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+struct fake_hip_stream { int unused; };
+struct fake_hip_event { std::atomic<long long> ready_at_ns; };
+typedef fake_hip_stream *hipStream_t;
+typedef fake_hip_event *hipEvent_t;
+
+extern std::atomic<long long> g_fake_gpu_latency_ns;   // defined by the test: how long a "batch" stays on the "GPU"
+
+inline long long fake_hip_now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorNotReady ? "not ready" : "fake hip error"; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new fake_hip_stream(); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new fake_hip_event(); (*e)->ready_at_ns.store(0); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->ready_at_ns.store(fake_hip_now_ns() + g_fake_gpu_latency_ns.load()); return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t e) { return fake_hip_now_ns() >= e->ready_at_ns.load() ? hipSuccess : hipErrorNotReady; }
+inline hipError_t hipEventSynchronize(hipEvent_t e) {
+  while (hipEventQuery(e) != hipSuccess) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  return hipSuccess;
+}
+#endif

@@ -1,0 +1,250 @@
+// ring_unit.cpp — TEST INFRASTRUCTURE.  Unit test of the ingest ring's HOST logic (csrc/crn_ingest.cpp compiled against
+// tests/harness/fake_hip: no GPU, ThreadSanitizer on): the caller thread and the ring's launcher thread share two batch
+// buffers, a work queue and a result queue; this drives every hand-off pattern and checks that each (stream, epoch) comes
+// back exactly once, in order per stream, carrying the checksum of exactly its own ten packets.
+//   sensing stand-in: features[0] of an epoch = sum of all its samples, features[1] = its first sample, decision = L.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>   // the stand-in under tests/harness/fake_hip
+
+#include "../../include/crn_sense.h"
+
+std::atomic<long long> g_fake_gpu_latency_ns(0);
+
+// ---- what crn_ingest.cpp links against in libcrnsense, restated for the test -----------------------------------------
+namespace crn {
+static thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace crn
+static std::atomic<int> g_fail_next_launch{0};
+extern "C" {
+const char *crn_last_error(void) { return crn::g_err.c_str(); }
+struct crn_handle { crn_cfg cfg; };
+int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
+int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o, void *) {
+  if (g_fail_next_launch.exchange(0)) return crn::fail(CRN_ERR_DEVICE, "forced launch failure");
+  const int K = h->cfg.frames_per_epoch, nb = h->cfg.n_bands;
+  for (int64_t e = 0; e < n_epochs; e++) {
+    const float *x = d_iq + (size_t)e * K * L * 2;
+    double s = 0;
+    for (int i = 0; i < K * L * 2; i++) s += x[i];
+    for (int b = 0; b < nb; b++) o->features[e * nb + b] = 0.f;
+    o->features[e * nb + 0] = (float)s;
+    o->features[e * nb + 1] = x[0];
+    o->decision[e] = L;
+    for (int k = 0; k < 3; k++) o->ann_out[e * 3 + k] = (double)k;
+    memset(o->occupancy + e * nb, 0, (size_t)nb);
+  }
+  return CRN_OK;
+}
+}
+
+#define REQUIRE(c)                                                            \
+  do {                                                                        \
+    if (!(c)) {                                                               \
+      fprintf(stderr, "ring_unit: line %d: %s FAILED\n", __LINE__, #c);      \
+      exit(1);                                                                \
+    }                                                                         \
+  } while (0)
+
+struct Feeder {   // deterministic packets: packet p of epoch e of stream s is filled with value(s, e, p)
+  int L;
+  static float value(int s, long e, int p) { return (float)(s * 1000 + e * 10 + p + 1); }
+  std::vector<float> packet(int s, long e, int p) const { return std::vector<float>((size_t)L * 2, value(s, e, p)); }
+  float checksum(int s, long e) const {
+    double t = 0;
+    for (int p = 0; p < 10; p++) t += (double)value(s, e, p) * L * 2;
+    return (float)t;
+  }
+};
+
+static void collect(crn_ingest *g, std::vector<crn_epoch_result> *all) {
+  crn_epoch_result r[16];
+  int32_t n = 0;
+  do {
+    REQUIRE(crn_ingest_poll(g, r, 16, &n) == CRN_OK);
+    all->insert(all->end(), r, r + n);
+  } while (n == 16);
+}
+
+static void verify(const std::vector<crn_epoch_result> &all, const Feeder &f, int streams, const std::vector<long> &epochs, long seq0 = 0) {
+  std::map<int, long> next;
+  size_t want = 0;
+  for (int s = 0; s < streams; s++) want += (size_t)epochs[s];
+  REQUIRE(all.size() == want);
+  for (const crn_epoch_result &r : all) {
+    REQUIRE(r.stream >= 0 && r.stream < streams);
+    const long e = r.epoch_seq - seq0;
+    REQUIRE(e == next[r.stream]);                  // in order per stream, none missing, none twice
+    next[r.stream] = e + 1;
+    REQUIRE(r.features[0] == f.checksum(r.stream, e));   // exactly its own ten packets
+    REQUIRE(r.features[1] == Feeder::value(r.stream, e, 0));
+    REQUIRE(r.decision == f.L);
+  }
+  for (int s = 0; s < streams; s++) REQUIRE(next[s] == epochs[s]);
+}
+
+int main() {
+  crn_handle h;
+  memset(&h, 0, sizeof(h));
+  h.cfg.fft_len = h.cfg.hop = 512;
+  h.cfg.frames_per_epoch = 10;
+  h.cfg.n_bands = 4;
+  h.cfg.decide = CRN_DECIDE_ANN;
+  crn_ingest *g = NULL;
+
+  // 1. argument checks
+  REQUIRE(crn_ingest_create(&h, 0, 364, 1, &g) == CRN_ERR_ARG);
+  REQUIRE(crn_ingest_create(&h, 1, 513, 1, &g) == CRN_ERR_ARG);
+
+  // 2. one stream, one epoch per batch (the engine's shape), instant "GPU"
+  {
+    Feeder f{364};
+    REQUIRE(crn_ingest_create(&h, 1, 512, 1, &g) == CRN_OK);
+    REQUIRE(crn_ingest_set_packet_len(g, 364) == CRN_OK);
+    std::vector<crn_epoch_result> all;
+    for (long e = 0; e < 50; e++)
+      for (int p = 0; p < 10; p++) {
+        std::vector<float> pk = f.packet(0, e, p);
+        int rc;
+        while ((rc = crn_ingest_push(g, 0, pk.data())) == CRN_ERR_BUSY) collect(g, &all);
+        REQUIRE(rc == CRN_OK);
+        collect(g, &all);
+      }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    verify(all, f, 1, {50});
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
+
+  // 3. slow "GPU" (2 ms per batch): push must refuse (BUSY), never wait; nothing is lost when the caller retries
+  {
+    Feeder f{100};
+    g_fake_gpu_latency_ns = 2000000;
+    REQUIRE(crn_ingest_create(&h, 1, 100, 1, &g) == CRN_OK);
+    std::vector<crn_epoch_result> all;
+    long busy = 0;
+    long long worst = 0;
+    for (long e = 0; e < 12; e++)
+      for (int p = 0; p < 10; p++) {
+        std::vector<float> pk = f.packet(0, e, p);
+        for (;;) {
+          const long long t0 = fake_hip_now_ns();
+          const int rc = crn_ingest_push(g, 0, pk.data());
+          const long long dt = fake_hip_now_ns() - t0;
+          if (dt > worst) worst = dt;
+          if (rc == CRN_OK) break;
+          REQUIRE(rc == CRN_ERR_BUSY);
+          busy++;
+          REQUIRE(crn_ingest_wait(g) == CRN_OK);   // a caller that must not drop waits explicitly
+        }
+      }
+    int64_t dropped = 0;
+    REQUIRE(crn_ingest_dropped(g, &dropped) == CRN_OK && dropped == busy && busy > 0);
+    REQUIRE(worst < 1500000);                      // no push ever sat out a 2 ms batch
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    verify(all, f, 1, {12});
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    g_fake_gpu_latency_ns = 0;
+  }
+
+  // 4. several streams round-robin, more streams than epochs per batch; then uneven rates (holes carried over); flush
+  for (int uneven = 0; uneven < 2; uneven++) {
+    Feeder f{64};
+    const int S = 5;
+    g_fake_gpu_latency_ns = uneven ? 200000 : 0;
+    REQUIRE(crn_ingest_create(&h, S, 64, 3, &g) == CRN_OK);
+    std::vector<crn_epoch_result> all;
+    std::vector<long> done(S, 0);
+    std::vector<int> pkt(S, 0);
+    const long target[S] = {9, 7, 5, 3, 1};
+    bool more = true;
+    long round = 0;
+    while (more) {
+      more = false;
+      for (int s = 0; s < S; s++) {
+        const int reps = uneven ? (S - s) : 1;     // stream 0 runs five times as fast as stream 4
+        for (int k = 0; k < reps && done[s] < target[s]; k++) {
+          std::vector<float> pk = f.packet(s, done[s], pkt[s]);
+          int rc;
+          while ((rc = crn_ingest_push(g, s, pk.data())) == CRN_ERR_BUSY) {
+            REQUIRE(crn_ingest_wait(g) == CRN_OK);
+            collect(g, &all);
+          }
+          REQUIRE(rc == CRN_OK);
+          if (++pkt[s] == 10) { pkt[s] = 0; done[s]++; }
+        }
+        if (done[s] < target[s]) more = true;
+      }
+      if (++round % 7 == 0) REQUIRE(crn_ingest_flush(g) == CRN_OK);   // flushes in the middle of epochs
+      collect(g, &all);
+    }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    verify(all, f, S, std::vector<long>(target, target + S));
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
+  g_fake_gpu_latency_ns = 0;
+
+  // 5. set_packet_len between epochs; refused while an epoch is staged
+  {
+    REQUIRE(crn_ingest_create(&h, 1, 256, 1, &g) == CRN_OK);
+    Feeder f{256};
+    std::vector<float> pk = f.packet(0, 0, 0);
+    REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+    REQUIRE(crn_ingest_set_packet_len(g, 128) == CRN_ERR_STATE);
+    REQUIRE(crn_ingest_set_packet_len(g, 257) == CRN_ERR_ARG);
+    for (int p = 1; p < 10; p++) {
+      pk = f.packet(0, 0, p);
+      REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+    }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    REQUIRE(crn_ingest_set_packet_len(g, 128) == CRN_OK);
+    Feeder f2{128};
+    for (int p = 0; p < 10; p++) {
+      pk = f2.packet(0, 1, p);
+      REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+    }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    std::vector<crn_epoch_result> all;
+    collect(g, &all);
+    REQUIRE(all.size() == 2 && all[0].decision == 256 && all[1].decision == 128);
+    REQUIRE(all[0].features[0] == f.checksum(0, 0) && all[1].features[0] == f2.checksum(0, 1));
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
+
+  // 6. a launch that fails on the launcher thread: the batch is dropped, the error surfaces once, the ring keeps working
+  {
+    Feeder f{32};
+    REQUIRE(crn_ingest_create(&h, 1, 32, 1, &g) == CRN_OK);
+    g_fail_next_launch = 1;
+    for (int p = 0; p < 10; p++) {
+      std::vector<float> pk = f.packet(0, 0, p);
+      REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+    }
+    const int rc = crn_ingest_drain(g);
+    REQUIRE(rc == CRN_ERR_DEVICE && strstr(crn_last_error(), "forced launch failure") != NULL);
+    std::vector<crn_epoch_result> all;
+    collect(g, &all);
+    REQUIRE(all.empty());
+    for (int p = 0; p < 10; p++) {
+      std::vector<float> pk = f.packet(0, 1, p);
+      REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+    }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    REQUIRE(all.size() == 1 && all[0].epoch_seq == 1 && all[0].features[0] == f.checksum(0, 1));
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
+  printf("ring_unit: ok\n");
+  return 0;
+}
