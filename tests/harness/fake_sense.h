@@ -1,0 +1,50 @@
+// fake_sense.h — TEST INFRASTRUCTURE: what csrc/crn_ingest.cpp (and the engine) link against in libcrnsense, restated for
+// CPU-only unit tests (ring_unit.cpp, engine_unit.cpp) together with tests/harness/fake_hip.  The sensing stand-in:
+//   features[0] of an epoch = sum of all its samples, features[1] = its first sample, decision = L (ring_unit) or
+//   the rounded first sample (engine_unit: g_fake_decision_from_data), ann_out = {0, 1, 2}.
+#ifndef CRN_FAKE_SENSE_H
+#define CRN_FAKE_SENSE_H
+#include <string.h>
+
+#include <atomic>
+#include <string>
+
+#include <hip/hip_runtime.h>   // the stand-in under tests/harness/fake_hip
+
+#include "../../include/crn_sense.h"
+
+std::atomic<long long> g_fake_gpu_latency_ns(0);
+
+// ---- what crn_ingest.cpp links against in libcrnsense, restated for the test -----------------------------------------
+namespace crn {
+static thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace crn
+static std::atomic<int> g_fail_next_launch{0};
+static std::atomic<int> g_fake_decision_from_data{0};
+extern "C" {
+const char *crn_last_error(void) { return crn::g_err.c_str(); }
+struct crn_handle { crn_cfg cfg; };
+int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
+int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o, void *) {
+  if (g_fail_next_launch.exchange(0)) return crn::fail(CRN_ERR_DEVICE, "forced launch failure");
+  const int K = h->cfg.frames_per_epoch, nb = h->cfg.n_bands;
+  for (int64_t e = 0; e < n_epochs; e++) {
+    const float *x = d_iq + (size_t)e * K * L * 2;
+    double s = 0;
+    for (int i = 0; i < K * L * 2; i++) s += x[i];
+    if (o->features) {   // any output may be NULL (crn_out)
+      for (int b = 0; b < nb; b++) o->features[e * nb + b] = 0.f;
+      o->features[e * nb + 0] = (float)s;
+      o->features[e * nb + 1] = x[0];
+    }
+    if (o->decision) o->decision[e] = g_fake_decision_from_data.load() ? (int)(x[0] + 0.5f) : L;
+    if (o->ann_out)
+      for (int k = 0; k < 3; k++) o->ann_out[e * 3 + k] = (double)k;
+    if (o->occupancy) memset(o->occupancy + e * nb, 0, (size_t)nb);
+  }
+  return CRN_OK;
+}
+}
+
+#endif

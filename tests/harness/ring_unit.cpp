@@ -17,35 +17,7 @@
 
 #include "../../include/crn_sense.h"
 
-std::atomic<long long> g_fake_gpu_latency_ns(0);
-
-// ---- what crn_ingest.cpp links against in libcrnsense, restated for the test -----------------------------------------
-namespace crn {
-static thread_local std::string g_err;
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
-}  // namespace crn
-static std::atomic<int> g_fail_next_launch{0};
-extern "C" {
-const char *crn_last_error(void) { return crn::g_err.c_str(); }
-struct crn_handle { crn_cfg cfg; };
-int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
-int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o, void *) {
-  if (g_fail_next_launch.exchange(0)) return crn::fail(CRN_ERR_DEVICE, "forced launch failure");
-  const int K = h->cfg.frames_per_epoch, nb = h->cfg.n_bands;
-  for (int64_t e = 0; e < n_epochs; e++) {
-    const float *x = d_iq + (size_t)e * K * L * 2;
-    double s = 0;
-    for (int i = 0; i < K * L * 2; i++) s += x[i];
-    for (int b = 0; b < nb; b++) o->features[e * nb + b] = 0.f;
-    o->features[e * nb + 0] = (float)s;
-    o->features[e * nb + 1] = x[0];
-    o->decision[e] = L;
-    for (int k = 0; k < 3; k++) o->ann_out[e * 3 + k] = (double)k;
-    memset(o->occupancy + e * nb, 0, (size_t)nb);
-  }
-  return CRN_OK;
-}
-}
+#include "fake_sense.h"
 
 #define REQUIRE(c)                                                            \
   do {                                                                        \

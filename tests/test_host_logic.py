@@ -1,0 +1,35 @@
+"""The ingest ring's HOST logic without a GPU: csrc/crn_ingest.cpp compiled against a host-only stand-in for the HIP
+runtime (tests/harness/fake_hip) and run under ThreadSanitizer (tests/harness/ring_unit.cpp): slot hand-out and single
+copy, the hand-off between the caller's thread and the ring's launcher thread, BUSY refusals with a slow "GPU" (push never
+waits), uneven stream rates (open epochs carried to the other buffer), flush in the middle of epochs, packet-length
+changes, and a launch that fails on the launcher thread — every (stream, epoch) exactly once, in order, carrying the
+checksum of exactly its own ten packets, and no data race reported."""
+import os
+import subprocess
+
+HARNESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness")
+
+
+def _run_unit(name, repeats):
+    exe = os.path.join(HARNESS, name)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HARNESS, exe])
+    for _ in range(repeats):   # thread interleavings differ from run to run
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert f"{name}: ok" in out.stdout
+        assert "ThreadSanitizer" not in out.stderr, out.stderr[:3000]
+
+
+def test_ring_host_logic_under_thread_sanitizer(built):
+    _run_unit("ring_unit", 5)
+
+
+def test_engine_control_flow_under_thread_sanitizer(built):
+    """tests/harness/engine_unit.cpp: CE_Predictive_Node_GPU::execute() over the real ring and the real crn_cfg_* helpers, the
+    sensing launch replaced by a stand-in that "decides" what the test put into the packets: first-call configuration
+    (CE_Predictive_Node.cpp:66-69), set_ce_sensing(0) on the 10th packet (:159), the set_tx_freq mapping incl. "ALL BUSY" (:245-261),
+    decisions reported by a later execute(), packets longer than the FFT truncated, a packet-length change between epochs, packets
+    refused (not waited for) while both buffers are "on the GPU", the synchronous mode, and the wall-clock gate (>= 100 ms between
+    sensing requests, each preceded by stop_tx: :127-141)."""
+    _run_unit("engine_unit", 2)
