@@ -10,12 +10,12 @@ import subprocess
 HARNESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness")
 
 
-def _run_unit(name, repeats):
+def _run_unit(name, repeats, *args):
     exe = os.path.join(HARNESS, name)
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HARNESS, exe])
     for _ in range(repeats):   # thread interleavings differ from run to run
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert f"{name}: ok" in out.stdout
         assert "ThreadSanitizer" not in out.stderr, out.stderr[:3000]
@@ -33,3 +33,11 @@ def test_engine_control_flow_under_thread_sanitizer(built):
     refused (not waited for) while both buffers are "on the GPU", the synchronous mode, and the wall-clock gate (>= 100 ms between
     sensing requests, each preceded by stop_tx: :127-141)."""
     _run_unit("engine_unit", 2)
+
+
+def test_occupancy_exchange_as_a_world_of_two_ranks(built):
+    """tests/harness/comm_unit.cpp: csrc/crn_comm.cpp with world = 2 — two threads, one communicator each, host stand-ins for the HIP
+    calls and tests/harness/libfake_rccl.so (really places rank r's block at offset r * count) behind $CRN_RCCL_LIB: every rank
+    receives [rank 0 block][rank 1 block], slots alternate and are reused, argument errors are refused.  The hardware run at N > 1
+    is the driver's; this is the same code path with everything but the wire."""
+    _run_unit("comm_unit", 3, os.path.join(HARNESS, "libfake_rccl.so"))
