@@ -359,16 +359,33 @@ CRN_API int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs,
  *  CRN_PU_MARKOV_INTENDED   the same chain with the thresholds its comments intend (`&&`): from
  *                           CH1/CH3: 0 -> CH1, 1..3 -> CH2, 4..9 -> CH3; from CH2: 0 -> CH1,
  *                           1..5 -> CH2, 6..9 -> CH3.  Never idle.
- * Markov models run per stream: the batch is n_streams consecutive runs of n_epochs / n_streams
- * epochs, each an independent chain started in CH1 (d_truth is required). */
-typedef enum crn_pu_model { CRN_PU_UNIFORM = 0, CRN_PU_MARKOV_AS_WRITTEN = 1, CRN_PU_MARKOV_INTENDED = 2 } crn_pu_model;
+ *  CRN_PU_SWEEP            the interferer's TX_FREQ_BEHAVIOR_SWEEP (src/interferer.cpp:339-345: step up by one
+ *                           resolution per dwell, reverse at either end) with one band per epoch:
+ *                           1, 2, .., n_active, n_active - 1, .., 1, 2, ..  Never idle.
+ * Markov and sweep models run per stream: the batch is n_streams consecutive runs of n_epochs / n_streams
+ * epochs, each started in CH1 (the Markov chains independent; d_truth is required for them). */
+typedef enum crn_pu_model { CRN_PU_UNIFORM = 0, CRN_PU_MARKOV_AS_WRITTEN = 1, CRN_PU_MARKOV_INTENDED = 2, CRN_PU_SWEEP = 3 } crn_pu_model;
 
-/* What the occupied band carries (src/interferer.cpp:128-140 CW / NOISE, :248-282 OFDM):
+/* What the occupied band carries (src/interferer.cpp:128-140 CW / NOISE, :160-215 GMSK, :221-248 RRC, :254-282 OFDM):
  *  CRN_SIG_TONES      tones_per_band on-grid tones spread over the band, fixed random phases per epoch
  *  CRN_SIG_CW         one carrier at the band's centre bin
  *  CRN_SIG_BAND_NOISE every bin of the band, fresh random phases every fft_len samples (a
- *                     frame-synchronous multicarrier burst: flat in-band spectrum) */
-typedef enum crn_signal_kind { CRN_SIG_TONES = 0, CRN_SIG_CW = 1, CRN_SIG_BAND_NOISE = 2 } crn_signal_kind;
+ *                     frame-synchronous multicarrier burst: flat in-band spectrum)
+ * The three below are continuous modulated carriers at the band's centre frequency (midway between its lowest and
+ * highest bin, bins >= fft_len / 2 counted as negative frequencies), NOT aligned to the FFT grid or to frames (they
+ * leak like a real transmitter); "band width" is the band's number of bins:
+ *  CRN_SIG_RRC_QPSK   random QPSK symbols through a root-raised-cosine pulse, roll-off 0.35 (RRC_BETA,
+ *                     include/interferer.hpp:21), truncated at +-8 symbols; symbol rate such that the occupied
+ *                     bandwidth (1 + beta) Rs is the band's width
+ *  CRN_SIG_GMSK       constant-envelope GMSK, BT = 0.5, modulation index 1/2 (the gmskframegen the interferer
+ *                     drives); symbol rate = band width / 1.5 (>= 99.9 % of the power inside the band)
+ *  CRN_SIG_OFDM       QPSK subcarriers 15 kHz apart at the 13 MHz sample rate of CE_Predictive_Node.hpp:42-43
+ *                     (the interferer's tx_rate / num_subcarriers, src/interferer.cpp:255), i.e.
+ *                     fft_len * 15e3 / 13e6 bins, filling the band; cyclic prefix 1/4 of the useful symbol, no taper
+ * All kinds have total power signal_rms^2. */
+typedef enum crn_signal_kind {
+  CRN_SIG_TONES = 0, CRN_SIG_CW = 1, CRN_SIG_BAND_NOISE = 2, CRN_SIG_RRC_QPSK = 3, CRN_SIG_GMSK = 4, CRN_SIG_OFDM = 5
+} crn_signal_kind;
 
 typedef struct crn_synth_cfg {
   uint64_t seed;

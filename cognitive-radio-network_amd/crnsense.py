@@ -68,8 +68,8 @@ class EpochResult(C.Structure):
 
 
 MONITOR_GNURADIO, MONITOR_PSD = 0, 1
-PU_UNIFORM, PU_MARKOV_AS_WRITTEN, PU_MARKOV_INTENDED = 0, 1, 2
-SIG_TONES, SIG_CW, SIG_BAND_NOISE = 0, 1, 2
+PU_UNIFORM, PU_MARKOV_AS_WRITTEN, PU_MARKOV_INTENDED, PU_SWEEP = 0, 1, 2, 3
+SIG_TONES, SIG_CW, SIG_BAND_NOISE, SIG_RRC_QPSK, SIG_GMSK, SIG_OFDM = 0, 1, 2, 3, 4, 5
 
 
 class SynthCfg(C.Structure):

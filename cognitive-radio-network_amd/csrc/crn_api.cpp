@@ -40,7 +40,7 @@ struct crn_handle {
   const float2 *d_tw1 = nullptr, *d_tw2 = nullptr;
   const float *d_window = nullptr, *d_thresh = nullptr;
   const int *d_band_seg_begin = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
-  const int *d_band_bins_begin = nullptr, *d_band_bins = nullptr, *d_band_tab = nullptr;
+  const int *d_band_bins_begin = nullptr, *d_band_bins = nullptr, *d_band_tab = nullptr, *d_band_c2 = nullptr;
   const double *d_wih = nullptr, *d_who = nullptr;
   // scratch of crn_sense_run_host
   void *d_scratch = nullptr;
@@ -192,6 +192,20 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     }
   }
 
+  // twice the signed centre of every band (bins >= N / 2 are negative frequencies; lowest + highest signed bin, so a band with a
+  // small gap in it — the reference plan's CH1 skips bins -1, -2 — is centred on its span): the carrier of the generator's
+  // modulated signal kinds
+  std::vector<int> band_c2(std::max(cfg->n_bands, 1), 0);
+  for (int b = 0; b < cfg->n_bands; b++) {
+    int lo = N, hi = -N;
+    for (int i = bins_begin[b]; i < bins_begin[b + 1]; i++) {
+      const int k = bins[i] >= N / 2 ? bins[i] - N : bins[i];
+      lo = std::min(lo, k);
+      hi = std::max(hi, k);
+    }
+    band_c2[b] = bins_begin[b + 1] > bins_begin[b] ? lo + hi : 0;
+  }
+
   struct Piece { const void *src; size_t bytes; size_t off; };
   std::vector<Piece> pieces = {
       {tw1.data(), tw1.size() * sizeof(float2), 0},
@@ -206,6 +220,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
       {cfg->ann_w_ih, sizeof(cfg->ann_w_ih), 0},
       {cfg->ann_w_ho, sizeof(cfg->ann_w_ho), 0},
       {band_tab.data(), band_tab.size() * sizeof(int), 0},
+      {band_c2.data(), band_c2.size() * sizeof(int), 0},
   };
   size_t total = 0;
   for (auto &p : pieces) {
@@ -238,6 +253,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   h->d_wih = reinterpret_cast<const double *>(base + pieces[9].off);
   h->d_who = reinterpret_cast<const double *>(base + pieces[10].off);
   h->d_band_tab = reinterpret_cast<const int *>(base + pieces[11].off);
+  h->d_band_c2 = reinterpret_cast<const int *>(base + pieces[12].off);
   *out = h;
   return CRN_OK;
 }
@@ -527,13 +543,14 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
   if (!h || !d_iq || !sc) return crn::fail(CRN_ERR_ARG, "null handle / configuration / IQ pointer");
   if (n_epochs < 0 || samples_per_epoch < 1) return crn::fail(CRN_ERR_ARG, "bad sizes");
   if (sc->tones_per_band < 0 || sc->noise_power < 0.f) return crn::fail(CRN_ERR_ARG, "bad signal parameters");
-  if (sc->pu_model < CRN_PU_UNIFORM || sc->pu_model > CRN_PU_MARKOV_INTENDED)
+  if (sc->pu_model < CRN_PU_UNIFORM || sc->pu_model > CRN_PU_SWEEP)
     return crn::fail(CRN_ERR_ARG, "unknown pu_model");
-  if (sc->signal_kind < CRN_SIG_TONES || sc->signal_kind > CRN_SIG_BAND_NOISE)
+  if (sc->signal_kind < CRN_SIG_TONES || sc->signal_kind > CRN_SIG_OFDM)
     return crn::fail(CRN_ERR_ARG, "unknown signal_kind");
   if (sc->n_streams < 1) return crn::fail(CRN_ERR_ARG, "n_streams must be >= 1");
+  const bool markov = sc->pu_model == CRN_PU_MARKOV_AS_WRITTEN || sc->pu_model == CRN_PU_MARKOV_INTENDED;
   if (sc->pu_model != CRN_PU_UNIFORM) {
-    if (!d_truth) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need d_truth");
+    if (markov && !d_truth) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need d_truth");
     if (n_epochs % sc->n_streams != 0) return crn::fail(CRN_ERR_ARG, "n_streams must divide n_epochs");
   }
   const crn_cfg &c = h->cfg;
@@ -561,11 +578,11 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
   if (sc->signal_kind == CRN_SIG_TONES && sc->tones_per_band == 0) p.n_active = 0;
   p.band_bins_begin = h->d_band_bins_begin;
   p.band_bins = h->d_band_bins;
+  p.band_c2 = h->d_band_c2;
   p.truth = d_truth;
-  if (sc->pu_model != CRN_PU_UNIFORM) {
-    if (p.n_active < 1) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need at least one driven band");
-    HIP_TRY(crn::launch_pu_pattern(p, static_cast<hipStream_t>(stream)));
-  }
+  if (sc->pu_model != CRN_PU_UNIFORM && p.n_active < 1)
+    return crn::fail(CRN_ERR_ARG, "the Markov and sweep traffic models need at least one driven band");
+  if (markov) HIP_TRY(crn::launch_pu_pattern(p, static_cast<hipStream_t>(stream)));
   HIP_TRY(crn::launch_synth(p, static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }

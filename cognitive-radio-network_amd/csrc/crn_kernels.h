@@ -67,6 +67,7 @@ struct SynthParams {
   int active_band0;   // first band index that can be picked
   const int *band_bins_begin;  // [n_bands + 1]
   const int *band_bins;        // flattened bin lists per band
+  const int *band_c2;          // [n_bands] twice the band's signed centre bin (modulated carriers)
   int32_t *truth;              // [n_epochs] or null
   int pu_model;                // crn_pu_model; the Markov models read truth[] (filled by launch_pu_pattern)
   int signal_kind;             // crn_signal_kind

@@ -1848,6 +1848,88 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
   return z ^ (z >> 31);
 }
 
+// ---- modulated carriers (CRN_SIG_RRC_QPSK / _GMSK / _OFDM, include/crn_sense.h).  Double precision on purpose: this is the test
+// signal source, not the sensing path, and the pulse formulas are 0/0 forms next to their removable singularities.
+constexpr double kPiD = 3.14159265358979323846;
+constexpr double kRrcBeta = 0.35;  // RRC_BETA, include/interferer.hpp:21
+constexpr int kRrcSemi = 8;        // symbols either side kept of the pulse
+
+__device__ __forceinline__ double rrc_pulse(double tau) {  // unit-energy root-raised-cosine, symbol period 1
+  const double q = 4.0 * kRrcBeta * tau;
+  if (fabs(tau) < 1e-9) return 1.0 - kRrcBeta + 4.0 * kRrcBeta / kPiD;
+  if (fabs(fabs(q) - 1.0) < 1e-9)
+    return kRrcBeta / sqrt(2.0) * ((1.0 + 2.0 / kPiD) * sin(kPiD / (4.0 * kRrcBeta)) + (1.0 - 2.0 / kPiD) * cos(kPiD / (4.0 * kRrcBeta)));
+  return (sin(kPiD * tau * (1.0 - kRrcBeta)) + q * cos(kPiD * tau * (1.0 + kRrcBeta))) / (kPiD * tau * (1.0 - q * q));
+}
+
+// GMSK phase pulse, BT = 0.5: the integral of a unit rectangle smoothed by a Gaussian of sigma = sqrt(ln 2) / (2 pi BT) symbols;
+// 0 well before the symbol, 1 well after.  F(x) = x Phi(x / sigma) + sigma phi(x / sigma) is the antiderivative of Phi(x / sigma).
+__device__ __forceinline__ double gmsk_ramp(double x) {
+  const double sigma = 0.26501095104247255;  // sqrt(ln 2) / pi
+  const double z = x / sigma;
+  return x * 0.5 * erfc(-z * 0.70710678118654752440) + sigma * 0.39894228040143267794 * exp(-0.5 * z * z);
+}
+__device__ __forceinline__ double gmsk_phase_pulse(double tau) { return gmsk_ramp(tau + 0.5) - gmsk_ramp(tau - 0.5); }
+
+// data bits of a GMSK burst: 64 per hash word, so that the running sum of +-1 up to any symbol costs one popcount per word
+__device__ __forceinline__ uint64_t gmsk_word(uint64_t hsig, long long j) { return mix64(hsig ^ mix64(0x6D5Bull + (uint64_t)j)); }
+__device__ __forceinline__ long long gmsk_prefix(uint64_t hsig, long long kk) {  // sum of b[0..kk], b = +-1
+  long long sum = 0;
+  const long long blk = kk >> 6;
+  for (long long j = 0; j < blk; j++) sum += 2 * __popcll(gmsk_word(hsig, j)) - 64;
+  const int cnt = (int)(kk & 63) + 1;
+  const uint64_t mask = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+  return sum + 2 * __popcll(gmsk_word(hsig, blk) & mask) - cnt;
+}
+
+// One sample (index m of its epoch) of the modulated carrier of `kind` filling a band of nb bins on an fft_len grid, before the
+// carrier: unit power.
+__device__ void modulated_baseband(int kind, uint64_t hsig, long long m, int nb, int fft_len, double *out_re, double *out_im) {
+  double re = 0.0, im = 0.0;
+  if (kind == 3) {  // RRC QPSK: (1 + beta) Rs = band width
+    const double sps = (double)fft_len * (1.0 + kRrcBeta) / (double)nb;
+    const double tau0 = (double)m / sps;
+    const long long k0 = (long long)floor(tau0);
+    for (long long k = k0 - kRrcSemi + 1; k <= k0 + kRrcSemi; k++) {
+      const uint64_t hs = mix64(hsig ^ mix64(0x5EEDull + (uint64_t)(k + 64)));
+      const double hv = rrc_pulse(tau0 - (double)k) * 0.70710678118654752440;
+      re += (hs & 1ull) ? hv : -hv;
+      im += (hs & 2ull) ? hv : -hv;
+    }
+  } else if (kind == 4) {  // GMSK: phase = pi / 2 * sum_k b_k q(t / T - k)
+    const double sps = 1.5 * (double)fft_len / (double)nb;
+    const double tau0 = (double)m / sps;
+    const long long k0 = (long long)floor(tau0);
+    double acc = (double)(gmsk_prefix(hsig, k0 - 3 + 8) & 3);   // symbols that have fully turned, modulo a full circle
+    for (long long k = k0 - 2; k <= k0 + 3; k++) {
+      const long long kk = k + 8;
+      const double b = ((gmsk_word(hsig, kk >> 6) >> (kk & 63)) & 1ull) ? 1.0 : -1.0;
+      acc += b * gmsk_phase_pulse(tau0 - (double)k);
+    }
+    re = cos(0.5 * kPiD * acc);
+    im = sin(0.5 * kPiD * acc);
+  } else {  // OFDM: subcarriers 15 kHz apart at 13 MHz, cyclic prefix 1/4
+    const double d = 15.0e3 / 13.0e6 * (double)fft_len;   // spacing in bins
+    const double tu = (double)fft_len / d, ts = 1.25 * tu;
+    int nsub = (int)floor((double)nb / d);
+    if (nsub < 1) nsub = 1;
+    const long long q = (long long)floor((double)m / ts);
+    const double t_in = (double)m - (double)q * ts - 0.25 * tu;
+    const double amp = 1.0 / sqrt(2.0 * (double)nsub);
+    for (int i = 0; i < nsub; i++) {
+      const uint64_t hs = mix64(hsig ^ mix64(0xFD0000000000ull + ((uint64_t)q << 20) + (uint64_t)i));
+      const double turns = ((double)i - 0.5 * (double)(nsub - 1)) * d * t_in / (double)fft_len;
+      const double a = 2.0 * kPiD * (turns - floor(turns));
+      const double c = cos(a), sn = sin(a);
+      const double ar = (hs & 1ull) ? amp : -amp, ai = (hs & 2ull) ? amp : -amp;
+      re += ar * c - ai * sn;
+      im += ar * sn + ai * c;
+    }
+  }
+  *out_re = re;
+  *out_im = im;
+}
+
 __global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
   const long long total = p.n_epochs * p.samples_per_epoch;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1864,8 +1946,28 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
 
     const uint64_t he = mix64(p.seed * 0x9E3779B97F4A7C15ull + (uint64_t)e + 0x51ED27ull);
     // uniform model: independent pick per epoch (0 = idle); Markov models: state written by pu_pattern_kernel
-    const int pick = p.pu_model == 0 ? (int)(he % (uint64_t)(p.n_active + 1)) : p.truth[e];
-    if (pick > 0) {
+    int pick;
+    if (p.pu_model == 0) {
+      pick = (int)(he % (uint64_t)(p.n_active + 1));
+    } else if (p.pu_model == 3) {  // sweep: up one band per epoch, reverse at either end (src/interferer.cpp:339-345)
+      const int period = 2 * (p.n_active - 1);
+      const int pos = period > 0 ? (int)((e % p.epochs_per_stream) % period) : 0;
+      pick = 1 + (pos < p.n_active ? pos : period - pos);
+    } else {
+      pick = p.truth[e];
+    }
+    if (pick > 0 && p.signal_kind >= 3) {
+      const int band = p.active_band0 + pick - 1;
+      const int nb = p.band_bins_begin[band + 1] - p.band_bins_begin[band];
+      double br, bi;
+      modulated_baseband(p.signal_kind, he, n, nb, p.fft_len, &br, &bi);
+      const long long two_n = 2ll * p.fft_len;
+      const long long c2 = ((long long)p.band_c2[band] % two_n + two_n) % two_n;
+      const double a = 2.0 * kPiD * (double)((c2 * (n % two_n)) % two_n) / (double)two_n;
+      const double c = cos(a), sn = sin(a);
+      re += (float)((double)p.signal_rms * (br * c - bi * sn));
+      im += (float)((double)p.signal_rms * (br * sn + bi * c));
+    } else if (pick > 0) {
       const int band = p.active_band0 + pick - 1;
       const int nb = p.band_bins_begin[band + 1] - p.band_bins_begin[band];
       const int *bins = p.band_bins + p.band_bins_begin[band];
@@ -1893,7 +1995,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
       }
     }
     p.iq[i] = make_float2(re, im);
-    if (n == 0 && p.truth != nullptr && p.pu_model == 0) p.truth[e] = pick;
+    if (n == 0 && p.truth != nullptr && (p.pu_model == 0 || p.pu_model == 3)) p.truth[e] = pick;
   }
 }
 

@@ -45,6 +45,31 @@ def test_twin_learns_the_1024_point_features(built):
     assert np.abs(got["ann_out"] - 0.8).min() > 0.1  # decisive, not marginal
 
 
+def test_twin_trained_on_modulated_carriers_decides_waveforms_it_has_not_seen(built):
+    """Features of the interferer's real waveforms (RRC QPSK, GMSK, OFDM: not aligned to the FFT grid, they leak) plus the on-grid
+    tones: one network fitted on the mixture decides fresh epochs of each, and of the band-filling multicarrier burst it never saw.
+    (A lone CW line is a different feature regime in the reference's square-of-sum-of-magnitudes definition — one bin instead of a
+    filled band at the same power — and stays out, as the shipped weights' single calibration point does: SURVEY.md §8f-3.)"""
+    cfg = _ref_mode_cfg(1024)
+    spe = cs.samples_per_epoch(cfg)
+    feats, labels = [], []
+    for i, sig in enumerate([cs.SIG_RRC_QPSK, cs.SIG_GMSK, cs.SIG_OFDM, cs.SIG_TONES]):
+        sc = _sc(40 + i)
+        sc.signal_kind = sig
+        iq, truth = orc.synth(cfg, sc, 192, spe)
+        feats.append(orc.run(cfg, iq, 192, n_threads=4)["features"])
+        labels.append(truth)
+    wih, who, loss = orc.ann_train(_tc(), np.concatenate(feats), np.concatenate(labels))
+    assert loss < 2e-3
+    for i, sig in enumerate([cs.SIG_RRC_QPSK, cs.SIG_GMSK, cs.SIG_OFDM, cs.SIG_TONES, cs.SIG_BAND_NOISE]):
+        sc = _sc(140 + i)
+        sc.signal_kind = sig
+        iq2, truth2 = orc.synth(cfg, sc, 64, spe)
+        got = orc.run(cs.set_ann_weights(_ref_mode_cfg(1024), wih, who), iq2, 64, n_threads=4)
+        assert np.array_equal(got["decision"], truth2), sig
+        assert np.abs(got["ann_out"] - 0.8).min() > 0.05, sig
+
+
 def test_twin_normalisation_is_folded_into_the_weights(built):
     """Training on features scaled by c with `normalise` gives W_IH rows scaled by 1/c and the same
     network function: inference needs no separate normalisation step."""
