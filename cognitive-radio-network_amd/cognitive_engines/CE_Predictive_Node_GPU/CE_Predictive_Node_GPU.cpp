@@ -42,11 +42,13 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   // which resets optind; CE_Template.cpp:17-25 shows the getopt idiom)
   int o;
   optind = 1;
-  while ((o = getopt(argc, argv, "a:d:g:v:")) != EOF) {
+  stats_on = 0;
+  while ((o = getopt(argc, argv, "a:d:g:s:v:")) != EOF) {
     switch (o) {
     case 'a': async_mode = atoi(optarg); break;            // 0: decide inside the K-th execute()
     case 'd': cfg.device = atoi(optarg); break;           // HIP device ordinal
     case 'g': wall_clock_gate = atoi(optarg) != 0; break;  // 0: sense continuously
+    case 's': stats_on = atoi(optarg); break;               // 1: time every launch, one summary line at release()
     case 'v': verbose = atoi(optarg); break;
     }
   }
@@ -59,6 +61,7 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   // replaces memset of the three buffers + fft_create_plan (.cpp:36-45)
   if (crn_sense_create(&cfg, &sensor) != CRN_OK) die_crn();
   if (crn_sense_reserve_host(sensor, 1, 0) != CRN_OK) die_crn();  // scratch + pinned staging + kernel load
+  if (stats_on && crn_sense_set_timing(sensor, 1) != CRN_OK) die_crn();
   if (async_mode) {
     // one stream, one epoch per batch; sized for full-length packets, the actual UHD packet length is
     // known only when the rx worker starts (src/extensible_cognitive_radio.cpp:1263-1265)
@@ -73,6 +76,24 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
 CE_Predictive_Node_GPU::~CE_Predictive_Node_GPU() { release(); }
 
 void CE_Predictive_Node_GPU::release() {
+  if (stats_on && sensor) {  // the counters of the C ABI (the reference has only its per-epoch printf lines)
+    crn_sense_stats ss;
+    crn_ingest_stats is;
+    memset(&ss, 0, sizeof(ss));
+    memset(&is, 0, sizeof(is));
+    if (ring) {
+      crn_ingest_drain(ring);
+      crn_ingest_get_stats(ring, &is);
+    }
+    crn_sense_get_stats(sensor, &ss);
+    printf("CE_Predictive_Node_GPU: epochs %lld  launches %lld  samples %lld  packets refused %lld  kernel %.1f us mean (%.1f .. %.1f)",
+           (long long)epochs_closed, (long long)ss.launches, (long long)ss.samples, (long long)packets_dropped,
+           ss.timed_launches ? 1e3 * ss.kernel_ms / (double)ss.timed_launches : 0.0, 1e3 * ss.kernel_ms_min, 1e3 * ss.kernel_ms_max);
+    if (ring)
+      printf("  hand-off to decision %.1f us mean, %.1f us max", is.batches ? is.latency_us_sum / (double)is.batches : 0.0,
+             is.latency_us_max);
+    printf("\n");
+  }
   if (ring) crn_ingest_destroy(ring);
   ring = NULL;
   if (sensor) crn_sense_destroy(sensor);

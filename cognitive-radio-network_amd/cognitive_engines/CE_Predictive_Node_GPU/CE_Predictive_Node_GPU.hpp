@@ -42,6 +42,7 @@ private:
   bool wall_clock_gate; // -g 0 disables the gettimeofday gate (deterministic offline runs)
   int async_mode;       // -a 0 selects the synchronous form
   int verbose;          // -v 0 silences the reference's printf block
+  int stats_on;         // -s 1: time every launch, print one summary line at release()
   int sensing_on;       // what this engine last told set_ce_sensing (the ECR's own flag is private)
   int frame_len;        // samples per staged packet, min(ce_usrp_rx_buffer_length, fft_len)
 

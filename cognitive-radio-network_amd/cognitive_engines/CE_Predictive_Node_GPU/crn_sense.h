@@ -245,6 +245,20 @@ CRN_API int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_re
 CRN_API int crn_ingest_drain(crn_ingest *g);
 /* Packets refused with CRN_ERR_BUSY so far. */
 CRN_API int crn_ingest_dropped(crn_ingest *g, int64_t *n_packets);
+/* Counters of a ring since its creation (the operational view the reference has only as printf lines: SURVEY.md §8b proposed
+ * `crn_sense_stats`).  Never blocks; call from the thread that pushes. */
+typedef struct crn_ingest_stats {
+  int64_t packets;           /* packets accepted */
+  int64_t dropped;           /* packets refused with CRN_ERR_BUSY */
+  int64_t batches;           /* launches (H2D + kernel + D2H) handed to the GPU */
+  int64_t batches_failed;    /* launches that failed (their epochs are lost; the error is reported once by the next call) */
+  int64_t epochs_launched;   /* epochs those batches carried */
+  int64_t epochs_ready;      /* epochs whose results came back */
+  int64_t epochs_polled;     /* of which crn_ingest_poll has handed out */
+  double latency_us_sum;     /* per batch: hand-off by the pushing thread -> results readable, summed over `batches` that came back */
+  double latency_us_max;
+} crn_ingest_stats;
+CRN_API int crn_ingest_get_stats(crn_ingest *g, crn_ingest_stats *out);
 CRN_API int crn_ingest_destroy(crn_ingest *g);
 
 /* -- multi-GPU: the occupancy exchange ----------------------------------------------------------
@@ -401,6 +415,22 @@ typedef struct crn_synth_cfg {
  * noise_power, signal_rms, tones, ..) == this with {CRN_PU_UNIFORM, CRN_SIG_TONES, n_streams 1}. */
 CRN_API int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq, int64_t n_epochs,
                                      int64_t samples_per_epoch, int32_t *d_truth, void *stream);
+
+/* Counters of a sensing handle since its creation.  `samples` counts every input sample a launch covers once (8 bytes each: the
+ * algorithmic read of the path), so samples * 8 / kernel seconds is the same figure bench.py's roofline reports.  Durations are
+ * measured only while crn_sense_set_timing(h, 1) is in effect (two HIP events per launch on the launch stream, a ring of 16 pairs;
+ * leave it off while capturing launches into a hipGraph); crn_sense_get_stats collects those that have finished and never blocks. */
+typedef struct crn_sense_stats {
+  int64_t launches;          /* crn_sense_run_device calls that launched (run_host and the ingest ring go through it) */
+  int64_t epochs;
+  int64_t samples;
+  int64_t timed_launches;    /* launches whose duration is in kernel_ms */
+  double kernel_ms;          /* sum of their durations */
+  double kernel_ms_last;
+  double kernel_ms_min, kernel_ms_max;
+} crn_sense_stats;
+CRN_API int crn_sense_set_timing(crn_handle *h, int32_t on);
+CRN_API int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out);
 
 /* Name, registers and LDS of the sensing kernel selected for this handle. */
 CRN_API int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *threads_per_block,

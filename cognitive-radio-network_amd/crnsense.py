@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense.so
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
 CRN_ABI_VERSION = 2
+CRN_ERR_ARG = -1
 CRN_ERR_BUSY = -5
 CRN_MAX_BANDS = 80
 CRN_MAX_SEGS = 160
@@ -29,7 +30,7 @@ EXPORTS = [
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
-    "crn_sense_reserve_host",
+    "crn_sense_reserve_host", "crn_sense_set_timing", "crn_sense_get_stats", "crn_ingest_get_stats",
     "crn_monitor_rows_device",
     "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
     "crn_comm_finish", "crn_comm_destroy",
@@ -70,6 +71,17 @@ class EpochResult(C.Structure):
 MONITOR_GNURADIO, MONITOR_PSD = 0, 1
 PU_UNIFORM, PU_MARKOV_AS_WRITTEN, PU_MARKOV_INTENDED, PU_SWEEP = 0, 1, 2, 3
 SIG_TONES, SIG_CW, SIG_BAND_NOISE, SIG_RRC_QPSK, SIG_GMSK, SIG_OFDM = 0, 1, 2, 3, 4, 5
+
+
+class SenseStats(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("epochs", C.c_int64), ("samples", C.c_int64), ("timed_launches", C.c_int64),
+                ("kernel_ms", C.c_double), ("kernel_ms_last", C.c_double), ("kernel_ms_min", C.c_double), ("kernel_ms_max", C.c_double)]
+
+
+class IngestStats(C.Structure):
+    _fields_ = [("packets", C.c_int64), ("dropped", C.c_int64), ("batches", C.c_int64), ("batches_failed", C.c_int64),
+                ("epochs_launched", C.c_int64), ("epochs_ready", C.c_int64), ("epochs_polled", C.c_int64),
+                ("latency_us_sum", C.c_double), ("latency_us_max", C.c_double)]
 
 
 class SynthCfg(C.Structure):
@@ -129,6 +141,9 @@ def lib():
         L.crn_ingest_wait.argtypes = [C.c_void_p]
         L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.crn_sense_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.crn_sense_get_stats.argtypes = [C.c_void_p, C.POINTER(SenseStats)]
+        L.crn_ingest_get_stats.argtypes = [C.c_void_p, C.POINTER(IngestStats)]
         L.crn_monitor_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.crn_comm_unique_id.argtypes = [C.c_void_p]
@@ -203,6 +218,14 @@ class Sensor:
 
     def set_variant(self, v):
         check(lib().crn_sense_set_variant(self._h, v), "crn_sense_set_variant")
+
+    def set_timing(self, on=True):
+        check(lib().crn_sense_set_timing(self._h, 1 if on else 0), "crn_sense_set_timing")
+
+    def stats(self):
+        st = SenseStats()
+        check(lib().crn_sense_get_stats(self._h, C.byref(st)), "crn_sense_get_stats")
+        return {k: getattr(st, k) for k, _ in SenseStats._fields_}
 
     def kernel_info(self):
         name = C.create_string_buffer(256)
@@ -364,6 +387,11 @@ class Ingest:
 
     def set_packet_len(self, L):
         check(lib().crn_ingest_set_packet_len(self._g, L), "crn_ingest_set_packet_len")
+
+    def stats(self):
+        st = IngestStats()
+        check(lib().crn_ingest_get_stats(self._g, C.byref(st)), "crn_ingest_get_stats")
+        return {k: getattr(st, k) for k, _ in IngestStats._fields_}
 
     def dropped(self):
         n = C.c_int64()

@@ -2,9 +2,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,6 +50,14 @@ struct crn_handle {
   double window_power = 0.0;   // sum of the squared fp32 window values (crn_monitor_rows_device)
   void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
   size_t h_results_bytes = 0;
+  // counters (crn_sense_get_stats): launches come from the caller's thread or from an ingest ring's launcher thread
+  std::atomic<int64_t> n_launches{0}, n_epochs{0}, n_samples{0};
+  std::mutex timing_mu;        // everything below
+  bool timing = false;
+  static constexpr int kTimedSlots = 16;
+  hipEvent_t t_start[kTimedSlots] = {}, t_stop[kTimedSlots] = {};
+  int64_t t_issued = 0, t_collected = 0, t_dropped = 0;   // slots [t_collected, t_issued) are in flight (mod kTimedSlots)
+  double kernel_ms = 0.0, kernel_ms_last = 0.0, kernel_ms_min = 0.0, kernel_ms_max = 0.0;
 };
 
 namespace {
@@ -264,6 +274,10 @@ int crn_sense_destroy(crn_handle *h) {
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_results) (void)hipHostFree(h->h_results);
   if (h->d_tables) (void)hipFree(h->d_tables);
+  for (int i = 0; i < crn_handle::kTimedSlots; i++) {
+    if (h->t_start[i]) (void)hipEventDestroy(h->t_start[i]);
+    if (h->t_stop[i]) (void)hipEventDestroy(h->t_stop[i]);
+  }
   delete h;
   return CRN_OK;
 }
@@ -337,6 +351,59 @@ static int resolve_strides(const crn_handle *h, int32_t L, int64_t *epoch_stride
   return CRN_OK;
 }
 
+namespace {
+// Collect the durations of timed launches that have finished (timing_mu held); `wait`: also the one occupying slot `must_free`.
+void collect_timings(crn_handle *h, bool wait_oldest) {
+  while (h->t_collected < h->t_issued) {
+    const int s = (int)(h->t_collected % crn_handle::kTimedSlots);
+    hipError_t q = hipEventQuery(h->t_stop[s]);
+    if (q == hipErrorNotReady && wait_oldest) q = hipEventSynchronize(h->t_stop[s]);
+    wait_oldest = false;
+    if (q == hipErrorNotReady) break;
+    float ms = 0.f;
+    if (q == hipSuccess && hipEventElapsedTime(&ms, h->t_start[s], h->t_stop[s]) == hipSuccess) {
+      const int64_t n = h->t_collected - h->t_dropped;
+      h->kernel_ms += ms;
+      h->kernel_ms_last = ms;
+      h->kernel_ms_min = n == 0 ? ms : std::min(h->kernel_ms_min, (double)ms);
+      h->kernel_ms_max = n == 0 ? ms : std::max(h->kernel_ms_max, (double)ms);
+    } else {
+      h->t_dropped++;   // a launch that failed on the device: no duration
+    }
+    h->t_collected++;
+  }
+}
+}  // namespace
+
+int crn_sense_set_timing(crn_handle *h, int32_t on) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->timing_mu);
+  if (on && !h->t_start[0]) {
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < crn_handle::kTimedSlots; i++) {
+      HIP_TRY(hipEventCreate(&h->t_start[i]));
+      HIP_TRY(hipEventCreate(&h->t_stop[i]));
+    }
+  }
+  h->timing = on != 0;
+  return CRN_OK;
+}
+
+int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out) {
+  if (!h || !out) return crn::fail(CRN_ERR_ARG, "null handle / stats");
+  std::lock_guard<std::mutex> lk(h->timing_mu);
+  collect_timings(h, false);
+  out->launches = h->n_launches.load(std::memory_order_relaxed);
+  out->epochs = h->n_epochs.load(std::memory_order_relaxed);
+  out->samples = h->n_samples.load(std::memory_order_relaxed);
+  out->timed_launches = h->t_collected - h->t_dropped;
+  out->kernel_ms = h->kernel_ms;
+  out->kernel_ms_last = h->kernel_ms_last;
+  out->kernel_ms_min = h->kernel_ms_min;
+  out->kernel_ms_max = h->kernel_ms_max;
+  return CRN_OK;
+}
+
 int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                          int64_t epoch_stride, const crn_out *d_out, void *stream) {
   if (!h || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / outputs");
@@ -399,8 +466,24 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   p.decision = d_out->decision;
   p.occupancy = d_out->occupancy;
   p.spectrum = d_out->spectrum;
-  HIP_TRY(crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT,
-                            h->variant, static_cast<hipStream_t>(stream)));
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(h->timing_mu);
+    if (h->timing) {
+      if (h->t_issued - h->t_collected == crn_handle::kTimedSlots) collect_timings(h, true);   // 16 launches behind: wait for the oldest
+      slot = (int)(h->t_issued++ % crn_handle::kTimedSlots);
+      HIP_TRY(hipEventRecord(h->t_start[slot], static_cast<hipStream_t>(stream)));
+    }
+  }
+  const hipError_t le = crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT, h->variant,
+                                          static_cast<hipStream_t>(stream));
+  if (slot >= 0) (void)hipEventRecord(h->t_stop[slot], static_cast<hipStream_t>(stream));   // also after a failed launch: the slot must complete
+  if (le != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("launch_sense: ") + hipGetErrorString(le));
+  // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
+  const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
+  h->n_launches.fetch_add(1, std::memory_order_relaxed);
+  h->n_epochs.fetch_add(n_epochs, std::memory_order_relaxed);
+  h->n_samples.fetch_add((n_epochs - 1) * std::min(epoch_stride, extent) + extent, std::memory_order_relaxed);
   return CRN_OK;
 }
 

@@ -56,6 +56,7 @@ struct Batch {
   int complete = 0;             // of which hold all K packets
   int launched = 0;             // slots of the launch handed to the launcher thread
   int L = 0;                    // packet length of that launch
+  std::chrono::steady_clock::time_point t_handoff;   // when the pushing thread handed it over (written before state = kQueued)
   std::atomic<int> state{kFree};
 };
 
@@ -74,6 +75,8 @@ struct crn_ingest {
   std::vector<int> open_slot;              // per stream: its slot in batch[fill], -1 = between epochs
   std::vector<int64_t> seq;                // per stream: epochs started
   int64_t dropped = 0;                     // packets refused with CRN_ERR_BUSY
+  int64_t packets = 0;                     // packets accepted
+  int64_t polled = 0;                      // results handed out
   // ---- shared with the launcher thread (under mu) ----
   std::mutex mu;
   std::condition_variable cv_work, cv_free;
@@ -82,6 +85,8 @@ struct crn_ingest {
   int err_code = CRN_OK;                   // first failure on the launcher thread, reported by the next call
   std::string err_msg;
   bool stop = false;
+  int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
+  double lat_us_sum = 0.0, lat_us_max = 0.0;
   std::thread launcher;
 };
 
@@ -156,8 +161,11 @@ void launcher_main(crn_ingest *g) {
           g->err_code = CRN_ERR_DEVICE;
           g->err_msg = "ingest launch failed, batch dropped: " + err;
         }
+        g->n_failed++;
         release_batch(g, g->batch[i]);
       } else {
+        g->n_batches++;
+        for (int sl = 0; sl < g->batch[i].launched; sl++) g->n_epochs_launched += g->batch[i].slots[sl].stream >= 0;   // holes carry nothing
         inflight.push_back(i);
       }
     }
@@ -174,8 +182,12 @@ void launcher_main(crn_ingest *g) {
     if (q == hipSuccess) {
       res.clear();
       collect(g, b, &res);
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b.t_handoff).count();
       lk.lock();
       for (const crn_epoch_result &r : res) g->ready.push_back(r);
+      g->n_epochs_ready += (int64_t)res.size();
+      g->lat_us_sum += us;
+      if (us > g->lat_us_max) g->lat_us_max = us;
       release_batch(g, b);
       inflight.pop_front();
       continue;
@@ -186,6 +198,7 @@ void launcher_main(crn_ingest *g) {
         g->err_code = CRN_ERR_DEVICE;
         g->err_msg = std::string("ingest batch failed on the device: ") + hipGetErrorString(q);
       }
+      g->n_failed++;
       release_batch(g, b);
       inflight.pop_front();
       continue;
@@ -234,6 +247,7 @@ int launch(crn_ingest *g) {
       sl.stream = -1;
     }
   }
+  b.t_handoff = std::chrono::steady_clock::now();
   b.state.store(kQueued, std::memory_order_release);
   {
     std::lock_guard<std::mutex> lk(g->mu);
@@ -347,6 +361,7 @@ int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) {
     Slot &s = b.slots[sl];
     std::memcpy(b.h_iq + (size_t)sl * g->epoch_floats + (size_t)s.npk * g->L * 2, iq_packet,
                 (size_t)g->L * 2 * sizeof(float));
+    g->packets++;
     if (++s.npk < g->K) return CRN_OK;
     g->open_slot[stream] = -1;
     b.complete++;
@@ -398,6 +413,7 @@ int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, i
       g->ready.pop_front();
     }
   }
+  g->polled += n;
   *n_out = n;
   return CRN_OK;
 }
@@ -413,6 +429,21 @@ int crn_ingest_drain(crn_ingest *g) {
 int crn_ingest_dropped(crn_ingest *g, int64_t *n_packets) {
   if (!g || !n_packets) return crn::fail(CRN_ERR_ARG, "null argument");
   *n_packets = g->dropped;
+  return CRN_OK;
+}
+
+int crn_ingest_get_stats(crn_ingest *g, crn_ingest_stats *out) {
+  if (!g || !out) return crn::fail(CRN_ERR_ARG, "null argument");
+  out->packets = g->packets;
+  out->dropped = g->dropped;
+  out->epochs_polled = g->polled;
+  std::lock_guard<std::mutex> lk(g->mu);
+  out->batches = g->n_batches;
+  out->batches_failed = g->n_failed;
+  out->epochs_launched = g->n_epochs_launched;
+  out->epochs_ready = g->n_epochs_ready;
+  out->latency_us_sum = g->lat_us_sum;
+  out->latency_us_max = g->lat_us_max;
   return CRN_OK;
 }
 

@@ -31,6 +31,14 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
 }
 int crn_sense_destroy(crn_handle *h) { delete h; return CRN_OK; }
 int crn_sense_reserve_host(crn_handle *, int64_t, int32_t) { return CRN_OK; }
+static int g_timing_requests = 0;
+int crn_sense_set_timing(crn_handle *, int32_t on) { g_timing_requests += on; return CRN_OK; }
+int crn_sense_get_stats(crn_handle *, crn_sense_stats *out) {
+  memset(out, 0, sizeof(*out));
+  out->launches = out->timed_launches = 7;
+  out->kernel_ms = 0.07;
+  return CRN_OK;
+}
 int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o) {
   return crn_sense_run_device(h, iq, n_epochs, L, 0, o, NULL);
 }
@@ -147,9 +155,10 @@ int main() {
   // ---- the wall-clock gate (default arguments): sensing is re-armed no sooner than every 100 ms (.cpp:127-141, .hpp:30) -----------
   {
     ECRd ecr;
-    char a0[] = "engine_unit", a1[] = "-v", a2[] = "0";
-    char *argv[] = {a0, a1, a2, NULL};
-    CE_Predictive_Node_GPU *e = new CE_Predictive_Node_GPU(3, argv, &ecr);
+    char a0[] = "engine_unit", a1[] = "-v", a2[] = "0", a3[] = "-s", a4[] = "1";   // -s 1: launches timed, summary line at release()
+    char *argv[] = {a0, a1, a2, a3, a4, NULL};
+    CE_Predictive_Node_GPU *e = new CE_Predictive_Node_GPU(5, argv, &ecr);
+    REQUIRE(g_timing_requests == 1);
     ecr.CE = e;
     std::vector<std::complex<float> > buf(364);
     ecr.ce_usrp_rx_buffer = buf.data();

@@ -94,6 +94,12 @@ int main() {
     REQUIRE(crn_ingest_drain(g) == CRN_OK);
     collect(g, &all);
     verify(all, f, 1, {50});
+    crn_ingest_stats st;
+    REQUIRE(crn_ingest_get_stats(g, &st) == CRN_OK);
+    REQUIRE(st.packets == 500 && st.batches == 50 && st.batches_failed == 0);
+    REQUIRE(st.epochs_launched == 50 && st.epochs_ready == 50 && st.epochs_polled == 50);
+    REQUIRE(st.latency_us_max > 0 && st.latency_us_sum >= st.latency_us_max && st.latency_us_max < 1e6);
+    REQUIRE(crn_ingest_get_stats(g, NULL) == CRN_ERR_ARG);
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
 
@@ -125,6 +131,10 @@ int main() {
     REQUIRE(crn_ingest_drain(g) == CRN_OK);
     collect(g, &all);
     verify(all, f, 1, {12});
+    crn_ingest_stats st;
+    REQUIRE(crn_ingest_get_stats(g, &st) == CRN_OK);
+    REQUIRE(st.packets == 120 && st.dropped == busy && st.batches == 12 && st.epochs_ready == 12);
+    REQUIRE(st.latency_us_sum / (double)st.batches > 1900.0);   // every batch sat out the stand-in's 2 ms
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
     g_fake_gpu_latency_ns = 0;
   }
@@ -163,6 +173,9 @@ int main() {
     REQUIRE(crn_ingest_drain(g) == CRN_OK);
     collect(g, &all);
     verify(all, f, S, std::vector<long>(target, target + S));
+    crn_ingest_stats st;
+    REQUIRE(crn_ingest_get_stats(g, &st) == CRN_OK);   // slots whose open epoch moved on to the other buffer carry nothing: not counted
+    REQUIRE(st.packets == 250 && st.epochs_launched == 25 && st.epochs_ready == 25 && st.epochs_polled == 25 && st.batches_failed == 0);
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
   g_fake_gpu_latency_ns = 0;
@@ -215,6 +228,9 @@ int main() {
     REQUIRE(crn_ingest_drain(g) == CRN_OK);
     collect(g, &all);
     REQUIRE(all.size() == 1 && all[0].epoch_seq == 1 && all[0].features[0] == f.checksum(0, 1));
+    crn_ingest_stats st;
+    REQUIRE(crn_ingest_get_stats(g, &st) == CRN_OK);
+    REQUIRE(st.packets == 20 && st.batches == 1 && st.batches_failed == 1 && st.epochs_launched == 1 && st.epochs_ready == 1);
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
   printf("ring_unit: ok\n");
