@@ -67,3 +67,61 @@ def test_no_cpu_fallback_without_gpu(built):
     with pytest.raises(cs.CrnError) as ei:
         cs.Sensor(cs.cfg_reference())
     assert "-2" in str(ei.value) or "device" in str(ei.value).lower()
+
+
+def _documented_valid(c):
+    """include/crn_sense.h, crn_cfg: the constraints crn_sense_create documents, restated."""
+    if c.abi_version != cs.CRN_ABI_VERSION or c.fft_len not in (512, 1024, 2048, 4096):
+        return False
+    if c.frames_per_epoch < 1 or not (1 <= c.hop <= c.fft_len):
+        return False
+    if c.mode not in (0, 1) or c.decide not in (0, 1, 2) or c.window not in (0, 1, 2):
+        return False
+    if not (1 <= c.n_bands <= cs.CRN_MAX_BANDS) or not (1 <= c.n_segs <= cs.CRN_MAX_SEGS):
+        return False
+    for i in range(c.n_segs):
+        g = c.segs[i]
+        if g.lo < 0 or g.hi > c.fft_len or g.lo > g.hi or not (0 <= g.band < c.n_bands):
+            return False
+    if c.decide == cs.DECIDE_ANN and c.n_bands != 4:
+        return False
+    if c.decide == cs.DECIDE_THRESHOLD and c.ref_band >= c.n_bands:
+        return False
+    return True
+
+
+def test_config_validation_fuzz(built):
+    """Random edits of valid configurations (edge values in every integer field, segments moved out of range): crn_sense_create
+    refuses exactly the ones the header documents as invalid with CRN_ERR_ARG before it touches the device, never crashes, and
+    never returns a handle for them.  (Without a GPU a valid configuration fails later, with CRN_ERR_DEVICE.)"""
+    import torch
+    from hypothesis import given, settings, strategies as st
+    has_gpu = torch.cuda.is_available()
+    L = cs.lib()
+    edge = st.sampled_from([-2 ** 31, -1, 0, 1, 2, 3, 4, 5, 64, 79, 80, 81, 160, 161, 511, 512, 513, 1024, 2048, 4095, 4096, 4097, 8192, 2 ** 31 - 1])
+    fields = ["abi_version", "fft_len", "frames_per_epoch", "hop", "mode", "decide", "window", "n_bands", "n_segs", "ref_band"]
+    bases = [cs.cfg_reference, lambda: cs.cfg_energy_scaled(4096, 4.0), lambda: cs.cfg_welch(4096, 8, 64), lambda: cs.cfg_welch(1024, 8, 64)]
+
+    @settings(max_examples=400, deadline=None)
+    @given(base=st.integers(0, len(bases) - 1),
+           edits=st.lists(st.tuples(st.sampled_from(fields), edge), min_size=0, max_size=3),
+           seg_edits=st.lists(st.tuples(st.integers(0, cs.CRN_MAX_SEGS - 1), st.sampled_from(["lo", "hi", "band"]), edge), min_size=0, max_size=2))
+    def check(base, edits, seg_edits):
+        c = bases[base]()
+        for f, v in edits:
+            setattr(c, f, v)
+        for i, f, v in seg_edits:
+            setattr(c.segs[i], f, v)
+        h = C.c_void_p()
+        rc = L.crn_sense_create(C.byref(c), C.byref(h))
+        if not _documented_valid(c):
+            assert rc == cs.CRN_ERR_ARG and not h.value, (rc, L.crn_last_error())
+        elif has_gpu:
+            # large-but-valid shapes may be refused for memory, never accepted wrongly
+            assert rc in (0, -3), (rc, L.crn_last_error())
+            if rc == 0:
+                L.crn_sense_destroy(h)
+        else:
+            assert rc == -2 and not h.value, (rc, L.crn_last_error())
+
+    check()
