@@ -1,0 +1,79 @@
+// ring_rate.cpp — how many radios one host thread can feed: S streams of reference-sized packets (364 samples) pushed round-robin
+// into one ingest ring (crn_ingest_*, C ABI only), decisions polled as they come.  Prints the sustained rate, what was refused and
+// the ring's own latency counters.  Build: make -C tests/harness ring_rate ; run on a GPU box: tools/ring_rate [streams] [epochs_per_batch] [seconds]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <random>
+#include <vector>
+
+#include "../include/crn_sense.h"
+
+#define CHECK(x)                                                       \
+  do {                                                                 \
+    if ((x) != CRN_OK) {                                               \
+      fprintf(stderr, "%s: %s\n", #x, crn_last_error());               \
+      return 1;                                                        \
+    }                                                                  \
+  } while (0)
+
+int main(int argc, char **argv) {
+  const int S = argc > 1 ? atoi(argv[1]) : 64;
+  const int B = argc > 2 ? atoi(argv[2]) : 256;
+  const double seconds = argc > 3 ? atof(argv[3]) : 3.0;
+  const int L = 364;
+  crn_cfg cfg;
+  CHECK(crn_cfg_reference(&cfg));
+  crn_handle *h = NULL;
+  CHECK(crn_sense_create(&cfg, &h));
+  CHECK(crn_sense_set_timing(h, 1));
+  crn_ingest *g = NULL;
+  CHECK(crn_ingest_create(h, S, L, B, &g));
+  // a few MB of packet data, walked cyclically (so that the source is not one cache-resident packet)
+  const int n_src = 4096;
+  std::vector<float> src((size_t)n_src * L * 2);
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1e-3f);
+  for (float &v : src) v = nd(rng);
+  std::vector<crn_epoch_result> res(1024);
+  long long pushed = 0, refused = 0, decisions = 0;
+  int32_t n = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  double elapsed = 0;
+  for (long long it = 0;; it++) {
+    for (int s = 0; s < S; s++) {
+      const float *pk = src.data() + (size_t)((it * S + s) % n_src) * L * 2;
+      const int rc = crn_ingest_push(g, s, pk);
+      if (rc == CRN_OK) pushed++;
+      else if (rc == CRN_ERR_BUSY) refused++;
+      else { fprintf(stderr, "push: %s\n", crn_last_error()); return 1; }
+    }
+    CHECK(crn_ingest_poll(g, res.data(), (int32_t)res.size(), &n));
+    decisions += n;
+    if ((it & 63) == 0) {
+      elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (elapsed >= seconds) break;
+    }
+  }
+  CHECK(crn_ingest_drain(g));
+  do {
+    CHECK(crn_ingest_poll(g, res.data(), (int32_t)res.size(), &n));
+    decisions += n;
+  } while (n > 0);
+  crn_ingest_stats st;
+  crn_sense_stats ss;
+  CHECK(crn_ingest_get_stats(g, &st));
+  CHECK(crn_sense_get_stats(h, &ss));
+  printf("ring_rate: %d streams x %d-sample packets, %d epochs per batch, one pushing thread, %.2f s\n", S, L, B, elapsed);
+  printf("  accepted %.1f Msamples/s (%.2f GB/s of IQ) = %.1f radios at 13 Msamples/s; refused %.2f %% of the packets offered\n",
+         pushed * (double)L / elapsed / 1e6, pushed * (double)L * 8 / elapsed / 1e9, pushed * (double)L / elapsed / 13e6,
+         100.0 * refused / (double)(pushed + refused));
+  printf("  decisions %lld (%.0f /s); batches %lld, hand-off to results %.0f us mean / %.0f us max; kernel %.1f us mean per batch\n", decisions,
+         decisions / elapsed, (long long)st.batches, st.batches ? st.latency_us_sum / st.batches : 0.0, st.latency_us_max,
+         ss.timed_launches ? 1e3 * ss.kernel_ms / ss.timed_launches : 0.0);
+  crn_ingest_destroy(g);
+  crn_sense_destroy(h);
+  return 0;
+}
