@@ -243,6 +243,18 @@ def main():
                                  stream=stream)
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
+    noise_floor = None
+    if args.mode in ("welch", "scan") and not args.zeros:
+        # SURVEY.md §8(d) cfg2 as worded: thr_b = lambda x NF_est, NF_est = the median band energy — measured on this rank's own
+        # batch (one untimed pass), not assumed: crn_noise_floor_device, then crn_sense_set_thresholds (which also updates `cfg`,
+        # so the oracle check below compares against the same f32 thresholds)
+        analytic = (args.fft / 64) * args.fft * 1e-6 * 0.375
+        sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
+        nf = sensor.noise_floor(feats.data_ptr(), E, stream=stream)
+        if not (0.8 * analytic < nf < 1.25 * analytic):
+            raise SystemExit(f"bench: noise-floor estimate {nf:.4g} is not near the generator's {analytic:.4g}")
+        sensor.set_thresholds([float(np.float32(4.0) * np.float32(nf))] * cfg.n_bands, stream=stream)
+        noise_floor = {"estimate_median_band_energy": nf, "generator_expectation": analytic, "lambda": 4.0}
     # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the
     # all-gather of step i (side stream) overlaps the sensing kernel of step i + 1
     ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world) if multi else (None, "")
@@ -497,6 +509,7 @@ def main():
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
                        "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
                        "parallelism": f"stream-sharded x{world}" + (", " + ex_kind if multi else ""),
+                       **({"noise_floor": noise_floor} if noise_floor else {}),
                        "alt": alt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -416,6 +416,15 @@ typedef struct crn_synth_cfg {
 CRN_API int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq, int64_t n_epochs,
                                      int64_t samples_per_epoch, int32_t *d_truth, void *stream);
 
+/* Noise-floor estimate for threshold plans (thr_b = lambda x NF_est, NF_est = the median band energy): the
+ * median over epochs of every epoch's median band energy, from a features matrix [n_epochs][n_bands] on the device (what
+ * crn_sense_run_device wrote; at most the first 4096 epochs are used).  "Median" = element (n - 1) / 2 of the sorted values.  With
+ * fewer than half of the bands occupied the estimate does not see the signals.  Enqueues on `stream` and waits for the result. */
+CRN_API int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream);
+/* Replace the per-band thresholds of a handle (cfg.thresh; CRN_DECIDE_THRESHOLD): ordered on `stream` — launches enqueued on it
+ * after the call see the new values, launches before it the old ones.  `thresh` is read before the call returns. */
+CRN_API int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream);
+
 /* Counters of a sensing handle since its creation.  `samples` counts every input sample a launch covers once (8 bytes each: the
  * algorithmic read of the path), so samples * 8 / kernel seconds is the same figure bench.py's roofline reports.  Durations are
  * measured only while crn_sense_set_timing(h, 1) is in effect (two HIP events per launch on the launch stream, a ring of 16 pairs;

@@ -30,6 +30,7 @@ EXPORTS = [
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
+    "crn_noise_floor_device", "crn_sense_set_thresholds",
     "crn_sense_reserve_host", "crn_sense_set_timing", "crn_sense_get_stats", "crn_ingest_get_stats",
     "crn_monitor_rows_device",
     "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
@@ -141,6 +142,8 @@ def lib():
         L.crn_ingest_wait.argtypes = [C.c_void_p]
         L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.crn_noise_floor_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
+        L.crn_sense_set_thresholds.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p]
         L.crn_sense_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.crn_sense_get_stats.argtypes = [C.c_void_p, C.POINTER(SenseStats)]
         L.crn_ingest_get_stats.argtypes = [C.c_void_p, C.POINTER(IngestStats)]
@@ -218,6 +221,19 @@ class Sensor:
 
     def set_variant(self, v):
         check(lib().crn_sense_set_variant(self._h, v), "crn_sense_set_variant")
+
+    def noise_floor(self, features_ptr, n_epochs, stream=0):
+        """Median over epochs of each epoch's median band energy (features [n_epochs][n_bands] on the device)."""
+        nf = C.c_float()
+        check(lib().crn_noise_floor_device(self._h, features_ptr, n_epochs, C.byref(nf), stream), "crn_noise_floor_device")
+        return nf.value
+
+    def set_thresholds(self, thresh, stream=0):
+        """Replace the per-band thresholds (ordered on `stream`); also updates self.cfg so that a checker sees the same values."""
+        arr = (C.c_float * len(thresh))(*[float(t) for t in thresh])
+        check(lib().crn_sense_set_thresholds(self._h, arr, len(thresh), stream), "crn_sense_set_thresholds")
+        for b, t in enumerate(arr):
+            self.cfg.thresh[b] = t
 
     def set_timing(self, on=True):
         check(lib().crn_sense_set_timing(self._h, 1 if on else 0), "crn_sense_set_timing")

@@ -48,6 +48,7 @@ struct crn_handle {
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
   double window_power = 0.0;   // sum of the squared fp32 window values (crn_monitor_rows_device)
+  float *d_nf_scratch = nullptr;   // crn_noise_floor_device: per-epoch medians + the result
   void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
   size_t h_results_bytes = 0;
   // counters (crn_sense_get_stats): launches come from the caller's thread or from an ingest ring's launcher thread
@@ -274,6 +275,7 @@ int crn_sense_destroy(crn_handle *h) {
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_results) (void)hipHostFree(h->h_results);
   if (h->d_tables) (void)hipFree(h->d_tables);
+  if (h->d_nf_scratch) (void)hipFree(h->d_nf_scratch);
   for (int i = 0; i < crn_handle::kTimedSlots; i++) {
     if (h->t_start[i]) (void)hipEventDestroy(h->t_start[i]);
     if (h->t_stop[i]) (void)hipEventDestroy(h->t_stop[i]);
@@ -562,6 +564,32 @@ int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t want_spect
   o.features = feat.data();
   o.spectrum = want_spectrum ? spec.data() : nullptr;
   return crn_sense_run_host(h, zeros.data(), max_epochs, c.fft_len, 0, &o);
+}
+
+int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream) {
+  if (!h || !d_features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
+  if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (!h->d_nf_scratch) HIP_TRY(hipMalloc(&h->d_nf_scratch, (crn::kNoiseFloorMaxEpochs + 1) * sizeof(float)));
+  const int n = (int)std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(crn::launch_noise_floor(d_features, n, h->cfg.n_bands, h->d_nf_scratch, st));
+  HIP_TRY(hipMemcpyAsync(nf_out, h->d_nf_scratch + crn::kNoiseFloorMaxEpochs, sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CRN_OK;
+}
+
+int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream) {
+  if (!h || !thresh) return crn::fail(CRN_ERR_ARG, "null handle / thresholds");
+  if (n_bands != h->cfg.n_bands) return crn::fail(CRN_ERR_ARG, "n_bands differs from the handle's");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
+  // the two device copies the kernels read: the table and the packed band table's threshold words (layout: crn_kernels.h).
+  // Pageable source: the runtime stages it before the call returns, the device copy is ordered on `stream`.
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(const_cast<float *>(h->d_thresh), h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 416, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
+  return CRN_OK;
 }
 
 int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,

@@ -103,6 +103,9 @@ struct MonitorParams {
   float *average_db;       // [n_rows][n] or null
 };
 hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream);
+// noise-floor estimate: scratch holds kNoiseFloorMaxEpochs per-epoch medians + the result
+constexpr int kNoiseFloorMaxEpochs = 4096;
+hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 

@@ -38,4 +38,43 @@ hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---- noise-floor estimate for threshold plans (crn_noise_floor_device, include/crn_sense.h) -------------------------------------
+// thr_b = lambda x NF_est, NF_est = the median band energy.  Lower median (element (n - 1) / 2 of the sorted
+// values) by rank counting: no sort, no scratch beyond one float per epoch, ties broken by index so that exactly one element wins.
+
+// one thread per epoch: the median of its n_bands band energies
+__global__ __launch_bounds__(256) void noise_floor_rows_kernel(const float *feat, int n_epochs, int nb, float *med) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_epochs) return;
+  const float *v = feat + (long long)e * nb;
+  const int want = (nb - 1) / 2;
+  for (int i = 0; i < nb; i++) {
+    const float vi = v[i];
+    int below = 0;
+    for (int j = 0; j < nb; j++) below += (v[j] < vi) || (v[j] == vi && j < i);
+    if (below == want) med[e] = vi;
+  }
+}
+
+// one workgroup: the median of the per-epoch medians (n <= 4096)
+__global__ __launch_bounds__(256) void noise_floor_final_kernel(const float *med, int n, float *out) {
+  extern __shared__ float sm[];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sm[i] = med[i];
+  __syncthreads();
+  const int want = (n - 1) / 2;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float vi = sm[i];
+    int below = 0;
+    for (int j = 0; j < n; j++) below += (sm[j] < vi) || (sm[j] == vi && j < i);
+    if (below == want) *out = vi;
+  }
+}
+
+hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream) {
+  hipLaunchKernelGGL(noise_floor_rows_kernel, dim3((unsigned)((n_epochs + 255) / 256)), dim3(256), 0, stream, feat, n_epochs, nb, scratch);
+  hipLaunchKernelGGL(noise_floor_final_kernel, dim3(1), dim3(256), (size_t)n_epochs * sizeof(float), stream, scratch, n_epochs,
+                     scratch + kNoiseFloorMaxEpochs);
+  return hipGetLastError();
+}
+
 }  // namespace crn
