@@ -10,6 +10,7 @@
 // its place in the gathered vector and prints one line.
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -60,8 +61,9 @@ int main(int argc, char **argv) {
 
   crn_cfg cfg;
   CHECK(crn_cfg_welch(&cfg, 4096, 8, 64));
-  // per-band threshold = 4 x the noise floor: 64 bins of Hann-windowed noise of power 1e-6 hold 64 x 4096 x 1e-6 x 3/8
-  for (int b = 0; b < 64; b++) cfg.thresh[b] = 4.0f * 64.0f * 4096.0f * 1e-6f * 0.375f;
+  // per-band threshold = 4 x the noise floor, measured below on this node's own streams (NF_est = the
+  // median band energy); until then nothing is flagged
+  for (int b = 0; b < 64; b++) cfg.thresh[b] = INFINITY;
   cfg.device = device;
   crn_handle *h = NULL;
   CHECK(crn_sense_create(&cfg, &h));
@@ -88,6 +90,20 @@ int main(int argc, char **argv) {
   sc.signal_kind = CRN_SIG_TONES;
   sc.n_streams = n_streams;
   CHECK(crn_synth_fill_device_ex(h, &sc, d_iq, E, spe, d_truth, stream));
+
+  {  // calibrate: one pass for the features, the median band energy, thresholds = 4 x it (64 x 4096 x 1e-6 x 3/8 = 0.098 expected)
+    crn_out o = {d_feat, NULL, NULL, NULL, NULL};
+    CHECK(crn_sense_run_device(h, d_iq, E, cfg.fft_len, 0, &o, stream));
+    float nf = 0.f, thr[64];
+    CHECK(crn_noise_floor_device(h, d_feat, E, &nf, stream));
+    if (!(nf > 0.08f && nf < 0.13f)) {
+      fprintf(stderr, "scan_node: rank %d: noise-floor estimate %g is off\n", rank, nf);
+      return 1;
+    }
+    for (int b = 0; b < 64; b++) thr[b] = 4.0f * nf;
+    CHECK(crn_sense_set_thresholds(h, thr, 64, stream));
+    if (rank == 0) printf("scan_node: noise floor (median band energy) %.5f -> thresholds %.5f\n", nf, 4.0f * nf);
+  }
 
   // the RCCL unique id: rank 0 makes it, the others pick it up from the file
   uint8_t id[CRN_COMM_ID_BYTES];
