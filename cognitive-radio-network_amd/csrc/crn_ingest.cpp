@@ -18,6 +18,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -85,6 +87,8 @@ struct crn_ingest {
   int err_code = CRN_OK;                   // first failure on the launcher thread, reported by the next call
   std::string err_msg;
   bool stop = false;
+  int spin_us = 150;                       // how long after a hand-off the launcher keeps polling before it sleeps ($CRN_INGEST_SPIN_US)
+  std::atomic<bool> work_waiting{false};   // work is not empty (read by the launcher without the lock while it polls an event)
   int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
   double lat_us_sum = 0.0, lat_us_max = 0.0;
   std::thread launcher;
@@ -153,6 +157,7 @@ void launcher_main(crn_ingest *g) {
     while (!g->work.empty()) {   // launch everything that is queued before waiting for anything
       const int i = g->work.front();
       g->work.pop_front();
+      if (g->work.empty()) g->work_waiting.store(false, std::memory_order_release);
       lk.unlock();
       const std::string err = enqueue(g, g->batch[i]);
       lk.lock();
@@ -176,9 +181,15 @@ void launcher_main(crn_ingest *g) {
     }
     Batch &b = g->batch[inflight.front()];
     lk.unlock();
-    // one epoch is back within tens of microseconds: look a few times before sleeping
-    hipError_t q = hipErrorNotReady;
-    for (int spin = 0; spin < 64 && q == hipErrorNotReady; spin++) q = hipEventQuery(b.done);
+    // a small batch (the engine's shape: one epoch) is back within ~50 us of its launch and a sleeping thread wakes up tens of
+    // microseconds late: keep looking for up to 150 us after the hand-off unless new work is waiting to be launched (hand-off to
+    // decision 106 -> 58 us).  Big batches take as long to fill as to run and polling through them costs the pushing thread
+    // 10-30 % of its rate (measured, tools/ring_rate): they sleep.
+    const bool small = (size_t)b.launched * (size_t)g->K * (size_t)b.L * 8 <= (size_t)512 * 1024;
+    const auto spin = std::chrono::microseconds(small ? g->spin_us : 0);
+    hipError_t q = hipEventQuery(b.done);
+    while (q == hipErrorNotReady && !g->work_waiting.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - b.t_handoff < spin)
+      q = hipEventQuery(b.done);
     if (q == hipSuccess) {
       res.clear();
       collect(g, b, &res);
@@ -252,6 +263,7 @@ int launch(crn_ingest *g) {
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->work.push_back(g->fill);
+    g->work_waiting.store(true, std::memory_order_release);
   }
   g->cv_work.notify_one();
   g->fill ^= 1;
@@ -317,6 +329,7 @@ int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_pack
     crn_ingest_destroy(g);
     return crn::fail(CRN_ERR_NOMEM, std::string("crn_ingest_create: ") + hipGetErrorString(e));
   }
+  if (const char *e = std::getenv("CRN_INGEST_SPIN_US")) g->spin_us = std::max(0, std::atoi(e));
   g->launcher = std::thread(launcher_main, g);
   *out = g;
   return CRN_OK;

@@ -9,11 +9,11 @@ iq, picks = signals.make_epochs(cfg, n_epochs, seed=5, L=L)
 iq.tofile("/tmp/iq_rate.bin")
 for name, mode in (("enqueue-only (default)", []), ("synchronous (-a 0)", ["-a", "0"])):
     t0 = time.perf_counter()
-    out = subprocess.run(["tests/harness/engine_harness", "/tmp/iq_rate.bin", str(L), "-g", "0", "-v", "0"] + mode, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(["tests/harness/engine_harness", "/tmp/iq_rate.bin", str(L), "-g", "0", "-v", "0", "-s", "1"] + mode, capture_output=True, text=True, timeout=600)
     dt = time.perf_counter() - t0
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("epoch ")]
     dec = np.array([int(l.split()[3]) for l in lines])
     print(f"engine {name}: {len(lines)} epochs, {(dec == picks[:len(dec)]).mean():.4f} correct, {dt:.2f} s wall incl. process start -> {len(lines) / dt:.0f} decisions/s ({len(lines) * 10 * L / dt / 1e6:.1f} Msamples/s; the radio delivers 13 Msamples/s)")
     for ln in out.stdout.splitlines():
-        if ln.startswith("execute_us") or ln.startswith("epoch_closing"):
+        if ln.startswith("execute_us") or ln.startswith("epoch_closing") or ln.startswith("CE_Predictive_Node_GPU:"):
             print("   ", ln)
