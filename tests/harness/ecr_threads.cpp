@@ -151,11 +151,14 @@ int main(int argc, char **argv) {
     }
     engine->packets_dropped = 0;
     s.ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::TIMEOUT;   // the event is consumed
-    if (engine->epochs_closed != seen && !awaiting.empty()) {
-      seen = engine->epochs_closed;
+    // one execute() may report more than one decision (two batches that came back together, e.g. after the launcher thread was
+    // descheduled): engine->decision is the last of them, the earlier ones are counted but cannot be attributed from here
+    while (engine->epochs_closed != seen && !awaiting.empty()) {
+      seen++;
       const std::vector<int> &segs = awaiting.front();
+      const bool last = seen == engine->epochs_closed;
       const bool pure = std::count(segs.begin(), segs.end(), segs[0]) == (long)segs.size();
-      printf("decision %d frames_from_segment %d pure %d t %.4f\n", engine->decision, segs[0], (int)pure, s.ecr.now());
+      printf("decision %d frames_from_segment %d pure %d t %.4f\n", last ? engine->decision : -1, segs[0], (int)(pure && last), s.ecr.now());
       awaiting.pop_front();
     }
     pthread_mutex_unlock(&s.CE_mutex);                   // :1803
