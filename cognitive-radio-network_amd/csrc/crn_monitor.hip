@@ -48,18 +48,23 @@ __global__ __launch_bounds__(256) void noise_floor_rows_kernel(const float *feat
   if (e >= n_epochs) return;
   const float *v = feat + (long long)e * nb;
   const int want = (nb - 1) / 2;
+  float m = __builtin_nanf("");   // a row holding a NaN has no median: the estimate says so instead of keeping a stale value
   for (int i = 0; i < nb; i++) {
     const float vi = v[i];
     int below = 0;
     for (int j = 0; j < nb; j++) below += (v[j] < vi) || (v[j] == vi && j < i);
-    if (below == want) med[e] = vi;
+    if (below == want) m = vi;
   }
+  for (int j = 0; j < nb; j++)
+    if (v[j] != v[j]) m = v[j];
+  med[e] = m;
 }
 
 // one workgroup: the median of the per-epoch medians (n <= 4096)
 __global__ __launch_bounds__(256) void noise_floor_final_kernel(const float *med, int n, float *out) {
   extern __shared__ float sm[];
   for (int i = threadIdx.x; i < n; i += blockDim.x) sm[i] = med[i];
+  if (threadIdx.x == 0) *out = __builtin_nanf("");
   __syncthreads();
   const int want = (n - 1) / 2;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -68,6 +73,9 @@ __global__ __launch_bounds__(256) void noise_floor_final_kernel(const float *med
     for (int j = 0; j < n; j++) below += (sm[j] < vi) || (sm[j] == vi && j < i);
     if (below == want) *out = vi;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (sm[i] != sm[i]) *out = sm[i];   // any epoch without a median: neither has the batch
 }
 
 hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream) {
