@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <mutex>
 #include <unordered_set>
 
@@ -30,6 +31,7 @@ struct fftplan_s {
   float *d_in, *d_out;
   hipStream_t stream;
   bool pinned_x, pinned_y;  // the caller's arrays page-locked for the copies (best effort)
+  float *map_x, *map_y;     // both non-null: the device's view of the page-locked arrays — the kernel reads x and writes y itself
 };
 
 namespace {
@@ -92,8 +94,20 @@ extern "C" fftplan fft_create_plan(unsigned int n, liquid_float_complex *x, liqu
       hipMalloc(&p->d_out, sizeof(float) * 2 * n) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess)
     die("device buffers", hipGetErrorString(hipGetLastError()));
   // page-lock the bound arrays: the two copies of every fft_execute then go straight over DMA
-  p->pinned_x = hipHostRegister(x, sizeof(float) * 2 * n, hipHostRegisterDefault) == hipSuccess;
-  p->pinned_y = hipHostRegister(y, sizeof(float) * 2 * n, hipHostRegisterDefault) == hipSuccess;
+  p->pinned_x = hipHostRegister(x, sizeof(float) * 2 * n, hipHostRegisterMapped) == hipSuccess;
+  p->pinned_y = hipHostRegister(y, sizeof(float) * 2 * n, hipHostRegisterMapped) == hipSuccess;
+  // A frame is 4-32 KiB: instead of upload + launch + download, the kernel reads the caller's x and writes the caller's y over
+  // the bus itself — one launch and one wait per fft_execute ($CRN_LIQUID_ZEROCOPY=0: the three-step form)
+  p->map_x = p->map_y = nullptr;
+  const char *zc = std::getenv("CRN_LIQUID_ZEROCOPY");
+  if (p->pinned_x && p->pinned_y && !(zc && zc[0] == '0')) {
+    void *dx = nullptr, *dy = nullptr;
+    if (hipHostGetDevicePointer(&dx, x, 0) == hipSuccess && hipHostGetDevicePointer(&dy, y, 0) == hipSuccess && dx && dy &&
+        (reinterpret_cast<uintptr_t>(dx) & 7u) == 0) {
+      p->map_x = static_cast<float *>(dx);
+      p->map_y = static_cast<float *>(dy);
+    }
+  }
   (void)hipGetLastError();
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -113,6 +127,13 @@ extern "C" void fft_execute(fftplan p) {
     static const plan_fn next = next_symbol<plan_fn>("fft_execute");
     if (!next) die("fft_execute: plan was not created by libcrnliquidfft and no other fft_execute follows it", nullptr);
     next(p);
+    return;
+  }
+  if (p->map_x) {
+    if (crn_fft_forward_device(p->h, p->map_x, 1, (int32_t)p->n, 0, p->map_y, p->stream) != CRN_OK)
+      die("crn_fft_forward_device", crn_last_error());
+    const hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) die("fft_execute", hipGetErrorString(e));
     return;
   }
   const size_t bytes = sizeof(float) * 2 * p->n;
