@@ -49,6 +49,8 @@ struct crn_handle {
   size_t scratch_bytes = 0;
   double window_power = 0.0;   // sum of the squared fp32 window values (crn_monitor_rows_device)
   float *d_nf_scratch = nullptr;   // crn_noise_floor_device: per-epoch medians + the result
+  void *h_small = nullptr;     // pinned in-place buffer of run_host's small batches (samples | results)
+  size_t h_small_bytes = 0;
   void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
   size_t h_results_bytes = 0;
   // counters (crn_sense_get_stats): launches come from the caller's thread or from an ingest ring's launcher thread
@@ -62,6 +64,8 @@ struct crn_handle {
 };
 
 namespace {
+
+constexpr size_t kInPlaceBytes = 512 * 1024;   // run_host batches up to this size are read and written in place by the kernel
 
 bool supported_n(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; }
 
@@ -274,6 +278,7 @@ int crn_sense_destroy(crn_handle *h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_results) (void)hipHostFree(h->h_results);
+  if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->d_nf_scratch) (void)hipFree(h->d_nf_scratch);
   for (int i = 0; i < crn_handle::kTimedSlots; i++) {
@@ -509,6 +514,35 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   const size_t b_occ = align_up((size_t)n_epochs * c.n_bands, 256);
   const size_t b_spec = out->spectrum ? align_up((size_t)n_epochs * c.fft_len * sizeof(float), 256) : 0;
   const size_t need = b_iq + b_feat + b_ann + b_dec + b_occ + b_spec;
+  const size_t res_bytes = b_feat + b_ann + b_dec + b_occ;
+  if (!out->spectrum && n_samples * 8 <= kInPlaceBytes) {
+    // A decision's worth of samples (the engine's synchronous form: one epoch of 10 x 512): staged in pinned memory that the
+    // kernel reads, and whose tail it writes the results to, over the bus itself — one launch and one wait instead of upload +
+    // launch + download.
+    if (b_iq + res_bytes > h->h_small_bytes) {
+      if (h->h_small) (void)hipHostFree(h->h_small);
+      h->h_small = nullptr;
+      h->h_small_bytes = 0;
+      hipError_t e = hipHostMalloc(&h->h_small, b_iq + res_bytes, hipHostMallocDefault);
+      if (e != hipSuccess) return crn::fail(CRN_ERR_NOMEM, std::string("hipHostMalloc(in-place staging): ") + hipGetErrorString(e));
+      h->h_small_bytes = b_iq + res_bytes;
+    }
+    char *b = static_cast<char *>(h->h_small);
+    std::memcpy(b, iq, n_samples * 8);
+    crn_out d{};
+    d.features = reinterpret_cast<float *>(b + b_iq);
+    d.ann_out = reinterpret_cast<double *>(b + b_iq + b_feat);
+    d.decision = reinterpret_cast<int32_t *>(b + b_iq + b_feat + b_ann);
+    d.occupancy = reinterpret_cast<uint8_t *>(b + b_iq + b_feat + b_ann + b_dec);
+    if (int rc = crn_sense_run_device(h, reinterpret_cast<const float *>(b), n_epochs, samples_per_frame, epoch_stride, &d, nullptr)) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    const char *r = b + b_iq;
+    if (out->features) std::memcpy(out->features, r, (size_t)n_epochs * c.n_bands * sizeof(float));
+    if (out->ann_out && c.decide == CRN_DECIDE_ANN) std::memcpy(out->ann_out, r + b_feat, (size_t)n_epochs * 3 * sizeof(double));
+    if (out->decision) std::memcpy(out->decision, r + b_feat + b_ann, (size_t)n_epochs * sizeof(int32_t));
+    if (out->occupancy) std::memcpy(out->occupancy, r + b_feat + b_ann + b_dec, (size_t)n_epochs * c.n_bands);
+    return CRN_OK;
+  }
   if (need > h->scratch_bytes) {
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     h->d_scratch = nullptr;
@@ -530,7 +564,6 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   if (int rc = crn_sense_run_device(h, d_iq, n_epochs, samples_per_frame, epoch_stride, &d, s)) return rc;
   // features | ann_out | decision | occupancy sit back to back in the scratch slab: one D2H into
   // pinned staging, then scatter on the host (a decision costs one upload, one launch, one download)
-  const size_t res_bytes = b_feat + b_ann + b_dec + b_occ;
   if (res_bytes > h->h_results_bytes) {
     if (h->h_results) (void)hipHostFree(h->h_results);
     h->h_results = nullptr;
