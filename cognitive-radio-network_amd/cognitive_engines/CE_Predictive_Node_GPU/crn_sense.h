@@ -409,6 +409,10 @@ typedef struct crn_synth_cfg {
   int32_t pu_model;       /* crn_pu_model */
   int32_t signal_kind;    /* crn_signal_kind */
   int32_t n_streams;      /* >= 1; must divide n_epochs for the Markov models */
+  int32_t adc_bits;       /* 0: full fp32 samples.  2..24: every component rounded to a multiple of 2^-(adc_bits - 1) and clipped to
+                           * [-1, 1): what a radio delivers — the reference's USRPs send 16-bit integers over the wire (4 bytes per
+                           * complex sample: the 363-364 samples of a 1500-byte packet, src/extensible_cognitive_radio.cpp:1263-1265),
+                           * which UHD converts to the complex floats of recv(.., COMPLEX_FLOAT32, ..) (:1071-1072) */
 } crn_synth_cfg;
 
 /* crn_synth_fill_device with a traffic model and a signal kind.  crn_synth_fill_device(.., seed,

@@ -88,7 +88,7 @@ class IngestStats(C.Structure):
 class SynthCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("noise_power", C.c_float), ("signal_rms", C.c_float),
                 ("tones_per_band", C.c_int32), ("pu_model", C.c_int32), ("signal_kind", C.c_int32),
-                ("n_streams", C.c_int32)]
+                ("n_streams", C.c_int32), ("adc_bits", C.c_int32)]
 
 
 class TrainCfg(C.Structure):

@@ -679,6 +679,7 @@ int crn_synth_fill_device(crn_handle *h, float *d_iq, int64_t n_epochs, int64_t 
   sc.pu_model = CRN_PU_UNIFORM;
   sc.signal_kind = CRN_SIG_TONES;
   sc.n_streams = 1;
+  sc.adc_bits = 0;
   return crn_synth_fill_device_ex(h, &sc, d_iq, n_epochs, samples_per_epoch, d_truth, stream);
 }
 
@@ -692,6 +693,7 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
   if (sc->signal_kind < CRN_SIG_TONES || sc->signal_kind > CRN_SIG_OFDM)
     return crn::fail(CRN_ERR_ARG, "unknown signal_kind");
   if (sc->n_streams < 1) return crn::fail(CRN_ERR_ARG, "n_streams must be >= 1");
+  if (sc->adc_bits != 0 && (sc->adc_bits < 2 || sc->adc_bits > 24)) return crn::fail(CRN_ERR_ARG, "adc_bits must be 0 or 2..24");
   const bool markov = sc->pu_model == CRN_PU_MARKOV_AS_WRITTEN || sc->pu_model == CRN_PU_MARKOV_INTENDED;
   if (sc->pu_model != CRN_PU_UNIFORM) {
     if (markov && !d_truth) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need d_truth");
@@ -711,6 +713,7 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
   p.pu_model = sc->pu_model;
   p.signal_kind = sc->signal_kind;
   p.epochs_per_stream = n_epochs / sc->n_streams;
+  p.adc_scale = sc->adc_bits ? (float)(1 << (sc->adc_bits - 1)) : 0.f;
   p.fft_len = c.fft_len;
   if (c.ref_band >= 0 || c.decide == CRN_DECIDE_ANN) {  // {NF, CH1, ..}: band 0 is never driven
     p.active_band0 = 1;

@@ -73,6 +73,7 @@ struct SynthParams {
   int signal_kind;             // crn_signal_kind
   float signal_rms;
   long long epochs_per_stream; // Markov models
+  float adc_scale;             // 0: off; 2^(adc_bits - 1): components rounded to multiples of 1 / adc_scale, clipped to [-1, 1)
 };
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,

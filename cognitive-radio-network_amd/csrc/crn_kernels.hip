@@ -1994,6 +1994,10 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthParams p) {
         im = fmaf(amp, s, im);
       }
     }
+    if (p.adc_scale > 0.f) {  // the radio's integer samples as UHD hands them over
+      re = fminf(fmaxf(rintf(re * p.adc_scale), -p.adc_scale), p.adc_scale - 1.f) / p.adc_scale;
+      im = fminf(fmaxf(rintf(im * p.adc_scale), -p.adc_scale), p.adc_scale - 1.f) / p.adc_scale;
+    }
     p.iq[i] = make_float2(re, im);
     if (n == 0 && p.truth != nullptr && (p.pu_model == 0 || p.pu_model == 3)) p.truth[e] = pick;
   }

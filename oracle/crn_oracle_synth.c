@@ -109,6 +109,7 @@ __attribute__((visibility("default")))
 int crn_oracle_synth(const crn_cfg *c, const crn_synth_cfg *sc, float *iq, int64_t n_epochs,
                      int64_t spe, int32_t *truth) {
   if (!c || !sc || !iq || !truth || n_epochs < 0 || spe < 1 || sc->n_streams < 1) return -1;
+  if (sc->adc_bits != 0 && (sc->adc_bits < 2 || sc->adc_bits > 24)) return -1;
   /* bins of every band, table order inside a band (as crn_sense_create lays them out) */
   int *begin = (int *)calloc((size_t)c->n_bands + 1, sizeof(int));
   int total = 0;
@@ -217,6 +218,11 @@ int crn_oracle_synth(const crn_cfg *c, const crn_synth_cfg *sc, float *iq, int64
           re = fmaf(amp, (float)cos(M_PI * (double)arg), re);
           im = fmaf(amp, (float)sin(M_PI * (double)arg), im);
         }
+      }
+      if (sc->adc_bits > 0) { /* the radio's integer samples (crn_synth_cfg.adc_bits) */
+        const float scale = (float)(1 << (sc->adc_bits - 1));
+        re = fminf(fmaxf(rintf(re * scale), -scale), scale - 1.f) / scale;
+        im = fminf(fmaxf(rintf(im * scale), -scale), scale - 1.f) / scale;
       }
       iq[2 * i] = re;
       iq[2 * i + 1] = im;

@@ -177,6 +177,30 @@ def test_oracle_decisions_follow_generated_traffic(built, pu):
     assert np.array_equal(got["decision"], truth)
 
 
+def test_adc_quantisation_of_the_twin(built):
+    """adc_bits = 16: the samples UHD hands the reference's engine (16-bit integers from the wire scaled to floats): every component
+    is a multiple of 2^-15 within half a step of the unquantised sample, clipped to [-1, 1); sensing decisions do not change."""
+    cfg = cs.cfg_reference()
+    spe = cs.samples_per_epoch(cfg)
+    n = 32
+    sc = _sc(seed=21, pu=cs.PU_UNIFORM)
+    full, truth = orc.synth(cfg, sc, n, spe)
+    sc.adc_bits = 16
+    q, truth_q = orc.synth(cfg, sc, n, spe)
+    assert np.array_equal(truth, truth_q)
+    k = q.astype(np.float64) * 32768.0
+    assert np.array_equal(k, np.round(k)) and np.abs(k).max() < 32768
+    assert np.abs(q.astype(np.float64) - full).max() <= 0.5 / 32768 + 1e-9
+    assert len(np.unique(q)) < 4000 < len(np.unique(full))
+    assert np.array_equal(orc.run(cfg, q, n)["decision"], truth)
+    sc.adc_bits, sc.signal_rms = 4, 3.0                                   # a coarse, overdriven converter clips
+    c, _ = orc.synth(cfg, sc, n, spe)
+    assert c.max() == 0.875 and c.min() == -1.0
+    import ctypes as C
+    sc.adc_bits = 1
+    assert orc.lib().crn_oracle_synth(C.byref(cfg), C.byref(sc), q.ctypes.data, n, spe, truth.ctypes.data) == -1
+
+
 def test_oracle_synth_rejects_bad_arguments(built):
     import ctypes as C
     cfg = cs.cfg_reference()
@@ -201,6 +225,7 @@ def test_device_modulated_carriers_match_twin(built, sig, mode):
     n_streams, eps = 3, 7
     n = n_streams * eps
     sc = _sc(seed=2000 + sig, pu=cs.PU_SWEEP, sig=sig, n_streams=n_streams)
+    sc.adc_bits = 16 if mode == "welch4096" else 0                      # one of the three plans through the 16-bit "radio"
     s = cs.Sensor(cfg)
     iq = torch.zeros(n * spe * 2, dtype=torch.float32, device=dev)
     truth = torch.full((n,), -1, dtype=torch.int32, device=dev)
@@ -209,7 +234,13 @@ def test_device_modulated_carriers_match_twin(built, sig, mode):
     want_iq, want_truth = orc.synth(cfg, sc, n, spe)
     assert np.array_equal(truth.cpu().numpy(), want_truth)
     scale = sc.signal_rms + np.sqrt(sc.noise_power)
-    assert np.abs(iq.cpu().numpy() - want_iq).max() < 1e-5 * scale
+    d = np.abs(iq.cpu().numpy() - want_iq)
+    if sc.adc_bits:   # a sample within rounding of a half step may land on either neighbour: rare, and exactly one step apart
+        step = 2.0 ** -(sc.adc_bits - 1)
+        off = d > 1e-5 * scale
+        assert off.mean() < 1e-3 and np.allclose(d[off], step, rtol=1e-6)
+    else:
+        assert d.max() < 1e-5 * scale
     if mode == "energy1024":
         got = s.run_host(iq.cpu().numpy(), n)
         want_occ = np.zeros((n, cfg.n_bands), np.uint8)

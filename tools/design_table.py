@@ -30,6 +30,8 @@ h = load("headline")
 rows.append(row("**headline: 4096-pt energy × 3ch + NF, K=10, 28 672 epochs** — kernel specialised to the reference channel plan's 7 of 16 pass-3 rows", h))
 rows.append(alt_row("same batch, no row pruning (`config.alt.unpruned`: any other band table, or spectrum output on)", h["config"]["alt"]["unpruned"]))
 rows.append(alt_row("same kernel, SURVEY.md §8(d)'s 2 GiB batch (`config.alt.cfgH_2GiB_batch`, 6 553 epochs)", h["config"]["alt"]["cfgH_2GiB_batch"]))
+if "adc16_input" in h["config"]["alt"]:
+    rows.append(alt_row("same batch and kernel, every sample rounded to the USRP's 16-bit wire format (`config.alt.adc16_input`: what the reference's radios deliver; §8)", h["config"]["alt"]["adc16_input"]))
 rows.append(row("same batch, epoch close reduced to an accumulator reset (`--variant 16`, ablation: not a sensing result)", load("ablation_no_epoch_close")))
 rows.append(row("cfg1: 1024-pt energy, 114 688 epochs", load("cfg1_1024pt")))
 rows.append(row("2048-pt energy, 57 344 epochs", load("energy_2048pt")))
