@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--span-events", action="store_true",
                     help="one event pair around all timed launches instead of one pair per launch")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
+    ap.add_argument("--adc-bits", type=int, default=0,
+                    help="round every input sample to this many bits (16 = the USRP wire format the reference's radios deliver); "
+                         "0 = full-precision fp32 (the default: SURVEY.md §8(d)'s generator, the worst case for power)")
     ap.add_argument("--zeros", action="store_true",
                     help="diagnostic, not a result: all-zero IQ (same instruction stream, least switching energy) — how much "
                          "of the kernel time is the clock the chip holds under load (implies --no-check, no CPU baseline)")
@@ -239,8 +242,12 @@ def main():
         truth.zero_()
         workload += " [DIAGNOSTIC: all-zero input]"
     else:
-        sensor.synth_fill_device(iq.data_ptr(), E, spe, seed=0xC0FFEE + 1000 * rank, truth_ptr=truth.data_ptr(),
-                                 stream=stream)
+        sc0 = cs.SynthCfg()
+        sc0.seed, sc0.noise_power, sc0.signal_rms, sc0.tones_per_band = 0xC0FFEE + 1000 * rank, 1e-6, 0.02, 8
+        sc0.pu_model, sc0.signal_kind, sc0.n_streams, sc0.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, args.adc_bits
+        sensor.synth_fill_device_ex(iq.data_ptr(), E, spe, sc0, truth_ptr=truth.data_ptr(), stream=stream)
+        if args.adc_bits:
+            workload += f" [DIAGNOSTIC INPUT: samples rounded to {args.adc_bits} bits, as a radio delivers them]"
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
     noise_floor = None
@@ -409,15 +416,16 @@ def main():
     # ---- config.alt: the same metric on SURVEY.md §8(d)'s 2 GiB batch, and without row pruning -------
     alt = None
     if rank == 0 and world == 1 and not multi and not args.no_alt and args.mode == "energy" and args.variant == 0 \
-            and args.epochs == 0 and args.frames == 0:
-        def leg(sn, epochs, n=50, src=None):
+            and args.epochs == 0 and args.frames == 0 and args.adc_bits == 0:
+        def leg(sn, epochs, n=50, src=None, dst=None):
             src = iq if src is None else src
+            dst = outs if dst is None else dst
             for _ in range(max(20, int(0.03 / 1.6e-3 * E / epochs))):
-                sn.run_device(src.data_ptr(), epochs, N, outs, stream=stream)
+                sn.run_device(src.data_ptr(), epochs, N, dst, stream=stream)
             pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
             for a, b in pairs:
                 a.record()
-                sn.run_device(src.data_ptr(), epochs, N, outs, stream=stream)
+                sn.run_device(src.data_ptr(), epochs, N, dst, stream=stream)
                 b.record()
             torch.cuda.synchronize()
             ms = [a.elapsed_time(b) for a, b in pairs]
@@ -440,11 +448,33 @@ def main():
         sc = cs.SynthCfg()
         sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 0xC0FFEE, 1e-6, 0.02, 8
         sc.pu_model, sc.signal_kind, sc.n_streams, sc.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, 16
-        sensor.synth_fill_device_ex(iq_q.data_ptr(), E, spe, sc, truth_ptr=truth.data_ptr(), stream=stream)
-        alt["adc16_input"] = dict(leg(sensor, E, src=iq_q), kernel=info["name"][:40] + "...",
-                                  note="same batch with every sample rounded to the USRP's 16-bit wire format (crn_synth_cfg.adc_bits = 16): "
-                                       "what the reference's radios deliver; the headline's full-precision fp32 noise is the worst case for power")
-        del iq_q
+        sensor.synth_fill_device_ex(iq_q.data_ptr(), E, spe, sc, stream=stream)
+        keep = [torch.empty_like(t) for t in (feats, ann, dec, occ)]   # its results go elsewhere: the checks below read the headline's
+        outs_q = {"features": keep[0].data_ptr(), "ann_out": keep[1].data_ptr(), "decision": keep[2].data_ptr(),
+                  "occupancy": keep[3].data_ptr(), "spectrum": 0}
+        # interleaved with the headline's own input, in blocks of 10 launches (~15 ms: long enough for the clock to settle, short
+        # enough that both inputs see the same package temperature), 6 blocks each, the first 3 launches of a block not counted
+        ms = {"fp32": [], "adc16": []}
+        for _ in range(6):
+            for name, src in (("fp32", iq), ("adc16", iq_q)):
+                pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for a, b in pairs:
+                    a.record()
+                    sensor.run_device(src.data_ptr(), E, N, outs_q, stream=stream)
+                    b.record()
+                torch.cuda.synchronize()
+                ms[name] += [a.elapsed_time(b) for a, b in pairs[3:]]
+
+        def frac_of(v):
+            return E * spe * 8 / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        alt["adc16_input"] = {"epochs": E, "bytes_per_step": E * spe * 8, "kernel_ms_mean": float(np.mean(ms["adc16"])),
+                              "kernel_ms_median": float(np.median(ms["adc16"])), "GB/s": frac_of(ms["adc16"]) * HBM_PEAK_GBS,
+                              "frac": frac_of(ms["adc16"]), "Msamples/s": E * spe / (float(np.mean(ms["adc16"])) * 1e-3) / 1e6,
+                              "frac_fp32_input_interleaved": frac_of(ms["fp32"]), "kernel": info["name"][:40] + "...",
+                              "note": "same batch with every sample rounded to the USRP's 16-bit wire format (crn_synth_cfg.adc_bits = 16): "
+                                      "what the reference's radios deliver; measured in blocks of 10 launches interleaved with the headline's "
+                                      "full-precision fp32 input (frac_fp32_input_interleaved), which is the worst case for power"}
+        del iq_q, keep
 
     # ---- CPU baseline ---------------------------------------------------------------------------------
     cpu = None

@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(*extra):
+def _run(*extra, epochs=("--epochs", "512")):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                          "--epochs", "512", *(() if "--live" in extra else ("--no-live-traffic",)),
+                          *epochs, *(() if "--live" in extra else ("--no-live-traffic",)),
                           *[e for e in extra if e != "--live"]], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -40,6 +40,18 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
     assert r["events"] == "per-launch" and r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"]
     assert d["metric"].startswith("Msamples/s IQ through FFT+energy-detect, 4096-pt x 3ch")
     assert d["config"]["workload"].startswith("4096-pt")
+
+
+def test_bench_default_batch_with_every_alt_leg_and_the_cpu_check(built):
+    """The driver's shape: the default 8.75 GiB batch, so that the config.alt legs run (2 GiB batch, unpruned kernel, 16-bit radio
+    samples) — and the CPU sample check after them still reads the headline launch's results, not a leg's."""
+    d = _run("--cpu-epochs", "64", epochs=())
+    alt = d["config"]["alt"]
+    assert set(alt) == {"cfgH_2GiB_batch", "unpruned", "adc16_input"}
+    for leg in alt.values():
+        assert 0.3 < leg["frac"] < 1.0 and leg["kernel_ms_mean"] > 0
+    assert alt["cfgH_2GiB_batch"]["bytes_per_step"] == 6553 * 40960 * 8
+    assert d["config"]["epochs_per_gpu"] == 28672 and d["cpu_baseline"]["value"] > 0
 
 
 def test_bench_measures_hbm_traffic_in_the_run(built):

@@ -18,6 +18,9 @@ timeout 300 python bench.py --mode scan --cpu-epochs 0 --force-collective > $O/b
 timeout 300 python bench.py --variant 16 --cpu-epochs 0 --no-check --no-alt > $O/bench_noclose.json 2> $O/bench_noclose.err
 timeout 300 python bench.py --fft 512 --cpu-epochs 0 > $O/bench_e512.json 2> $O/bench_e512.err
 timeout 300 python bench.py --fft 2048 --cpu-epochs 0 > $O/bench_e2048.json 2> $O/bench_e2048.err
+# the same kernels on samples rounded to the USRP's 16-bit wire format (what the reference's radios deliver): diagnostic lines
+{ for m in "--mode welch" "--mode ref" "--fft 1024" "--fft 2048"; do timeout 300 python bench.py $m --adc-bits 16 --cpu-epochs 0 --no-live-traffic --no-alt 2>/dev/null | tail -1; done; } > $O/bench_adc16.jsonl
+timeout 120 tools/ring_rate 64 256 3 > $O/ring_rate.txt 2>&1; timeout 60 tools/ring_rate 1 1 3 >> $O/ring_rate.txt 2>&1
 ./tools/membw_policy > $O/membw_policy.txt 2>&1
 timeout 300 python tools/host_rate.py > $O/host_rate.txt 2>&1
 timeout 300 python tools/engine_rate.py > $O/engine_rate.txt 2>&1
