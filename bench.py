@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--span-events", action="store_true",
                     help="one event pair around all timed launches instead of one pair per launch")
     ap.add_argument("--no-check", action="store_true", help="skip output checks (ablation variants only)")
+    ap.add_argument("--wire-format", action="store_true",
+                    help="keep the samples in HBM in the radio's wire format (int16 pairs, 4 bytes per complex sample: "
+                         "crn_sense_run_device_sc16) instead of complex floats; implies --adc-bits 16.  Not the headline configuration")
     ap.add_argument("--adc-bits", type=int, default=0,
                     help="round every input sample to this many bits (16 = the USRP wire format the reference's radios deliver); "
                          "0 = full-precision fp32 (the default: SURVEY.md §8(d)'s generator, the worst case for power)")
@@ -242,12 +245,20 @@ def main():
         truth.zero_()
         workload += " [DIAGNOSTIC: all-zero input]"
     else:
+        if args.wire_format:
+            args.adc_bits, args.no_alt, args.no_live_traffic = 16, True, True
         sc0 = cs.SynthCfg()
         sc0.seed, sc0.noise_power, sc0.signal_rms, sc0.tones_per_band = 0xC0FFEE + 1000 * rank, 1e-6, 0.02, 8
         sc0.pu_model, sc0.signal_kind, sc0.n_streams, sc0.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, args.adc_bits
         sensor.synth_fill_device_ex(iq.data_ptr(), E, spe, sc0, truth_ptr=truth.data_ptr(), stream=stream)
         if args.adc_bits:
             workload += f" [DIAGNOSTIC INPUT: samples rounded to {args.adc_bits} bits, as a radio delivers them]"
+    src, sample_bytes = iq, 8
+    if args.wire_format and not args.zeros:
+        wire = torch.empty(n_samples * 2, dtype=torch.int16, device=dev)
+        sensor.pack_sc16_device(iq.data_ptr(), n_samples, wire.data_ptr(), stream=stream)
+        src, sample_bytes = wire, 4
+        workload += " [NOT THE HEADLINE CONFIGURATION: samples held in HBM in the radio's wire format, int16 pairs = 4 B per sample, converted in the kernel's first pass; outputs bit-identical to the float path]"
     outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
             "occupancy": occ.data_ptr(), "spectrum": 0}
     noise_floor = None
@@ -256,7 +267,7 @@ def main():
         # batch (one untimed pass), not assumed: crn_noise_floor_device, then crn_sense_set_thresholds (which also updates `cfg`,
         # so the oracle check below compares against the same f32 thresholds)
         analytic = (args.fft / 64) * args.fft * 1e-6 * 0.375
-        sensor.run_device(iq.data_ptr(), E, N, outs, stream=stream)
+        sensor.run_device(src.data_ptr(), E, N, outs, stream=stream, sc16=sample_bytes == 4)
         nf = sensor.noise_floor(feats.data_ptr(), E, stream=stream)
         if not (0.8 * analytic < nf < 1.25 * analytic):
             raise SystemExit(f"bench: noise-floor estimate {nf:.4g} is not near the generator's {analytic:.4g}")
@@ -273,7 +284,7 @@ def main():
             out_ptrs["occupancy"] = ex.local_ptr(n_done, stream)
         if ev is not None:
             ev[0].record()
-        sn.run_device(iq.data_ptr(), epochs, N, out_ptrs, stream=stream)
+        sn.run_device(src.data_ptr(), epochs, N, out_ptrs, stream=stream, sc16=sample_bytes == 4)
         if ev is not None:
             ev[1].record()
         if ex is not None:
@@ -319,7 +330,7 @@ def main():
     kern_ms_mean = float(np.mean(kern_ms))
     samples_per_step = E * spe * world
     value = samples_per_step * args.steps / dt / 1e6  # Msamples/s, whole job
-    algo_bytes = E * spe * 8                          # per launch: 8 B per unique input sample
+    algo_bytes = E * spe * sample_bytes               # per launch: 8 B per unique input sample (4 in wire format)
     achieved = algo_bytes / (kern_ms_mean * 1e-3) / 1e9
 
     # ---- sanity on the timed outputs ----------------------------------------------------------------
@@ -377,7 +388,7 @@ def main():
         # HBM bytes per launch, measured now: two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a
         # pass on gfx950) over a short child run of this same workload — a child process, started while this one idles.
         traffic, traffic_source = live_traffic(args, E)
-    if traffic is None:
+    if traffic is None and not args.wire_format:   # (the committed figures are for complex-float input)
         tj = committed(args.traffic_json, mode_key)
         if tj:  # measured once per kernel with rocprofv3 PMC passes of this command; scales linearly with the batch
             traffic = int(tj["hbm_bytes_per_launch"] * (E / tj["epochs"]))
@@ -474,7 +485,27 @@ def main():
                               "note": "same batch with every sample rounded to the USRP's 16-bit wire format (crn_synth_cfg.adc_bits = 16): "
                                       "what the reference's radios deliver; measured in blocks of 10 launches interleaved with the headline's "
                                       "full-precision fp32 input (frac_fp32_input_interleaved), which is the worst case for power"}
-        del iq_q, keep
+        # ... and held in HBM in that wire format (int16 pairs, 4 B per complex sample: crn_sense_run_device_sc16): half the bytes
+        # per sample, converted in the kernel's first pass, outputs bit-identical to the float path on the same samples
+        wire = torch.empty(n_samples * 2, dtype=torch.int16, device=dev)
+        sensor.pack_sc16_device(iq_q.data_ptr(), n_samples, wire.data_ptr(), stream=stream)
+        for _ in range(20):
+            sensor.run_device(wire.data_ptr(), E, N, outs_q, stream=stream, sc16=True)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for a, b in pairs:
+            a.record()
+            sensor.run_device(wire.data_ptr(), E, N, outs_q, stream=stream, sc16=True)
+            b.record()
+        torch.cuda.synchronize()
+        wms = [a.elapsed_time(b) for a, b in pairs]
+        wgbs = E * spe * 4 / (float(np.mean(wms)) * 1e-3) / 1e9
+        alt["wire_format_sc16"] = {"epochs": E, "bytes_per_step": E * spe * 4, "kernel_ms_mean": float(np.mean(wms)),
+                                   "kernel_ms_median": float(np.median(wms)), "GB/s": wgbs, "frac": wgbs / HBM_PEAK_GBS,
+                                   "Msamples/s": E * spe / (float(np.mean(wms)) * 1e-3) / 1e6,
+                                   "note": "NOT the headline configuration (which reads complex floats, 8 B per sample): the same samples as "
+                                           "adc16_input kept in HBM as int16 pairs, 4 B per sample; the kernel is then bound by the vector "
+                                           "unit at the power cap, not by HBM, so Msamples/s is the figure to read, not frac"}
+        del iq_q, keep, wire
 
     # ---- CPU baseline ---------------------------------------------------------------------------------
     cpu = None

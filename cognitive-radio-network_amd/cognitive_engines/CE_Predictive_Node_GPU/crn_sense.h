@@ -185,6 +185,17 @@ CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epo
                          int32_t samples_per_frame, int64_t epoch_stride,
                          const crn_out *d_out, void *stream);
 
+/* crn_sense_run_device on samples kept in the radio's WIRE FORMAT: two int16 per complex sample (re, im; full scale 32768), 4 bytes
+ * instead of 8 — what the reference's USRPs put on the network (src/extensible_cognitive_radio.cpp:1263-1265: 363-364 samples per
+ * 1500-byte packet) and UHD's recv converts to the complex floats of ce_usrp_rx_buffer (:1071-1072).  The kernel converts in its
+ * first pass (int16 / 32768, exact in fp32), so every output is bit-identical to crn_sense_run_device on the converted floats,
+ * while HBM holds and streams half the bytes.  Same arguments otherwise (strides in samples; d_iq 4-byte aligned).  Provided for
+ * unwindowed plans and for the Welch configuration (periodic Hann, whole frames, energy mode): CRN_ERR_ARG otherwise. */
+CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                                      int64_t epoch_stride, const crn_out *d_out, void *stream);
+/* Complex floats -> wire format on the device (rounded to the nearest of the 65536 levels, clipped): n_samples complex samples. */
+CRN_API int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream);
+
 /* Host-buffer convenience used by the engine wrapper: H2D, run, D2H, synchronise. */
 CRN_API int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs,
                        int32_t samples_per_frame, int64_t epoch_stride, const crn_out *out);

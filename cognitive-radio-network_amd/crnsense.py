@@ -26,6 +26,7 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
+    "crn_sense_run_device_sc16", "crn_pack_sc16_device",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
@@ -110,6 +111,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CrnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # A process that uses both PyTorch and this library must load PyTorch first: the wheel bundles its own ROCm runtime, and when
+        # /opt/rocm's copy (which libcrnsense links) is loaded before it the two HSA runtimes collide — the library then reports
+        # "no ROCm-capable device is detected".  Tests and bench.py use torch for device memory, so pin the order here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.crn_last_error.restype = C.c_char_p
         L.crn_cfg_reference.argtypes = [C.POINTER(Cfg)]
@@ -119,6 +127,9 @@ def lib():
         L.crn_sense_destroy.argtypes = [C.c_void_p]
         L.crn_sense_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                            C.POINTER(Out), C.c_void_p]
+        L.crn_sense_run_device_sc16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                                C.POINTER(Out), C.c_void_p]
+        L.crn_pack_sc16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.crn_sense_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                          C.POINTER(Out)]
         L.crn_synth_fill_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
@@ -251,11 +262,17 @@ class Sensor:
         return {"name": name.value.decode(), "threads_per_block": thr.value, "lds_bytes": lds.value,
                 "epochs_per_block": epb.value}
 
-    def run_device(self, iq_ptr, n_epochs, L, out_ptrs, stream=0, epoch_stride=0):
-        """iq_ptr / out_ptrs: raw device addresses (ints); out_ptrs keys are Out fields."""
+    def run_device(self, iq_ptr, n_epochs, L, out_ptrs, stream=0, epoch_stride=0, sc16=False):
+        """iq_ptr / out_ptrs: raw device addresses (ints); out_ptrs keys are Out fields.  sc16: iq_ptr holds the radio's wire
+        format (int16 pairs, 4 bytes per complex sample)."""
         o = Out(**{k: (v or None) for k, v in out_ptrs.items()})
-        check(lib().crn_sense_run_device(self._h, iq_ptr, n_epochs, L, epoch_stride, C.byref(o),
-                                         C.c_void_p(stream or None)), "crn_sense_run_device")
+        fn = lib().crn_sense_run_device_sc16 if sc16 else lib().crn_sense_run_device
+        check(fn(self._h, iq_ptr, n_epochs, L, epoch_stride, C.byref(o), C.c_void_p(stream or None)),
+              "crn_sense_run_device_sc16" if sc16 else "crn_sense_run_device")
+
+    def pack_sc16_device(self, iq_ptr, n_samples, out_ptr, stream=0):
+        """complex floats -> int16 pairs on the device (n_samples complex samples)."""
+        check(lib().crn_pack_sc16_device(self._h, iq_ptr, n_samples, out_ptr, C.c_void_p(stream or None)), "crn_pack_sc16_device")
 
     def run_host(self, iq, n_epochs, L=None, want_spectrum=False, epoch_stride=0):
         """iq: numpy float32 array of interleaved samples. Returns dict of numpy outputs."""

@@ -411,23 +411,25 @@ int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out) {
   return CRN_OK;
 }
 
-int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t samples_per_frame,
-                         int64_t epoch_stride, const crn_out *d_out, void *stream) {
+static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                           int64_t epoch_stride, const crn_out *d_out, void *stream, bool sc16) {
   if (!h || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / outputs");
   if (n_epochs < 0) return crn::fail(CRN_ERR_ARG, "n_epochs < 0");
   if (n_epochs == 0) return CRN_OK;
   if (!d_iq) return crn::fail(CRN_ERR_ARG, "null IQ pointer");
-  if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) != 0) return crn::fail(CRN_ERR_ARG, "IQ pointer must be 8-byte aligned");
+  const int64_t sample_bytes = sc16 ? 4 : 8;
+  if ((reinterpret_cast<uintptr_t>(d_iq) & (uintptr_t)(sample_bytes - 1)) != 0)
+    return crn::fail(CRN_ERR_ARG, sc16 ? "IQ pointer must be 4-byte aligned" : "IQ pointer must be 8-byte aligned");
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
   HIP_TRY(hipSetDevice(h->cfg.device));  // a NULL stream / a launch follows the calling thread's current device
   // a workgroup addresses its window with 32-bit byte offsets
-  if ((64 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * 8 >= ((int64_t)1 << 31))
+  if ((64 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * sample_bytes >= ((int64_t)1 << 31))
     return crn::fail(CRN_ERR_ARG, "epoch_stride too large (a workgroup window must stay below 2 GiB)");
   const crn_cfg &c = h->cfg;
   crn::SenseParams p{};
-  p.iq = reinterpret_cast<const float2 *>(d_iq);
+  p.iq = reinterpret_cast<const float2 *>(d_iq);   // int16 pairs when sc16: the kernel instantiation knows
   p.n_epochs = n_epochs;
   p.epoch_stride = epoch_stride;
   p.total_samples = (n_epochs - 1) * epoch_stride + (int64_t)(c.frames_per_epoch - 1) * frame_stride +
@@ -483,14 +485,35 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
     }
   }
   const hipError_t le = crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT, h->variant,
-                                          static_cast<hipStream_t>(stream));
+                                          static_cast<hipStream_t>(stream), sc16);
   if (slot >= 0) (void)hipEventRecord(h->t_stop[slot], static_cast<hipStream_t>(stream));   // also after a failed launch: the slot must complete
+  if (le == hipErrorNotSupported)
+    return crn::fail(CRN_ERR_ARG, "wire-format input is provided for unwindowed plans and for the Welch configuration (periodic Hann, "
+                                  "whole frames, energy mode) only");
   if (le != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("launch_sense: ") + hipGetErrorString(le));
   // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
   const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
   h->n_launches.fetch_add(1, std::memory_order_relaxed);
   h->n_epochs.fetch_add(n_epochs, std::memory_order_relaxed);
   h->n_samples.fetch_add((n_epochs - 1) * std::min(epoch_stride, extent) + extent, std::memory_order_relaxed);
+  return CRN_OK;
+}
+
+int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                         int64_t epoch_stride, const crn_out *d_out, void *stream) {
+  return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, false);
+}
+
+int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                              int64_t epoch_stride, const crn_out *d_out, void *stream) {
+  return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, true);
+}
+
+int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream) {
+  if (!h || !d_iq || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
+  if (n_samples < 0) return crn::fail(CRN_ERR_ARG, "n_samples < 0");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(crn::launch_pack_sc16(d_iq, n_samples, d_out, static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }
 

@@ -77,7 +77,7 @@ struct SynthParams {
 };
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
-                        hipStream_t stream);
+                        hipStream_t stream, bool sc16 = false);
 int sense_num_variants();
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
@@ -108,6 +108,7 @@ hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream);
 constexpr int kNoiseFloorMaxEpochs = 4096;
 hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
+hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 
 }  // namespace crn

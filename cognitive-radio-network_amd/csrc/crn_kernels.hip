@@ -311,10 +311,33 @@ __host__ __device__ constexpr int spec_phys(int k) { return k + (k >> 4); }  // 
 // without touching memory.
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
-template <bool NT>
+template <bool NT, bool SC = false>
 CRN_DEV cx ld_iq(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, NT ? 2 : 0);
-  return cx{__uint_as_float(v.x), __uint_as_float(v.y)};
+  if constexpr (SC) {  // wire format: one dword = (int16 re, int16 im); kept raw until pass 1 consumes it (unpack_frame)
+    const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, NT ? 2 : 0);
+    return cx{__uint_as_float(w), 0.f};
+  } else {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, NT ? 2 : 0);
+    return cx{__uint_as_float(v.x), __uint_as_float(v.y)};
+  }
+}
+
+// Wire-format samples (kSc16) become floats where a frame's registers are consumed: exactly what UHD's converter hands the
+// reference's engine — int16 / 32768, both steps exact in fp32 — so every later bit is the bit the float path computes.
+CRN_DEV void unpack_frame(cx (&u)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int w = (int)__float_as_uint(u[r].x);
+    u[r] = cx{(float)(short)(w & 0xffff), (float)(w >> 16)};
+  }
+}
+// The 1 / 32768 of that conversion is a power of two: it commutes with every rounding on the way (butterflies, |X|, the K-frame
+// mean), so it is applied once per epoch where the accumulated sums leave the frame loop — 2^-15 on a sum of magnitudes,
+// 2^-30 on a sum of energies — instead of twice per sample, and the results stay bit-identical to the float path's.
+template <class C>
+CRN_DEV float sc_unscale(float x) {
+  if constexpr (C::SC16) return x * (C::MAG ? 0x1p-15f : 0x1p-30f);
+  else return x;
 }
 
 // u[r] = x[t + T r] of the frame that starts `frame_soff` bytes into the workgroup's window.
@@ -324,20 +347,22 @@ constexpr unsigned kOffNowhere = 0x80000000u;  // scalar offset past every windo
 
 // Rows that lie wholly beyond the L samples a frame brings (short packets: the reference's 364 of
 // 512, CE_Predictive_Node.cpp:149) are not fetched at all: they would be the next frame's samples.
-template <int R3, bool NT>
+template <int R3, bool NT, bool SC = false>
 CRN_DEV void load_frame(cx (&u)[16], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned frame_soff, int L = Geo<R3>::N) {
   constexpr int T = Geo<R3>::T;
+  constexpr int SB = SC ? 4 : 8;
 #pragma unroll
-  for (int r = 0; r < 16; r++) u[r] = ld_iq<NT>(rsrc, voff, T * r < L ? frame_soff + (unsigned)(T * r * 8) : kOffNowhere);
+  for (int r = 0; r < 16; r++) u[r] = ld_iq<NT, SC>(rsrc, voff, T * r < L ? frame_soff + (unsigned)(T * r * SB) : kOffNowhere);
 }
 
 // Half a frame: h[r] = x[t + T r], r = 0..7, of the N/2 samples starting `half_soff` bytes into the
 // window (Welch mode: consecutive frames share a half, so each half is fetched once).
-template <int R3, bool NT>
+template <int R3, bool NT, bool SC = false>
 CRN_DEV void load_half(cx (&h)[8], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned half_soff) {
   constexpr int T = Geo<R3>::T;
+  constexpr int SB = SC ? 4 : 8;
 #pragma unroll
-  for (int r = 0; r < 8; r++) h[r] = ld_iq<NT>(rsrc, voff, half_soff + (unsigned)(T * r * 8));
+  for (int r = 0; r < 8; r++) h[r] = ld_iq<NT, SC>(rsrc, voff, half_soff + (unsigned)(T * r * SB));
 }
 
 // Zero padding of a short frame (L < N), applied when the registers are consumed (reference: the
@@ -387,6 +412,7 @@ enum : int {
   kHannSym = 16384, // periodic Hann folded into pass 1's first butterflies (w[n + N/2] = 1 - w[n]): 8 window registers
   kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
   kAlignedBands = 65536, // N = 4096, equal contiguous bands of 64 / 128 / 256 bins (p.aligned_shift): band sums by DPP + one barrier
+  kSc16 = 131072,   // samples in HBM are the radio's wire format (two int16 per complex sample, 4 bytes): converted in pass 1
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -396,6 +422,8 @@ struct Cfg {
   static constexpr int R3 = R3_, NBUF = NBUF_, OCC = OCC_, ABL = ABL_;
   static constexpr bool PREFETCH = PREFETCH_, NT = NT_, MAG = MAG_, WIN = WIN_, TW2LDS = TW2LDS_, FULL = FULL_,
                         PK = PK_;
+  static constexpr bool SC16 = (OPT_ & 131072) != 0;   // kSc16
+  static constexpr unsigned SB = SC16 ? 4u : 8u;       // bytes per complex sample in HBM
 };
 
 // Per-thread state that lives across the frames of an epoch.
@@ -418,7 +446,7 @@ struct FrameCtx {
 // Drops the next frame's loads into the current frame's butterfly stream one at a time: a wave
 // that issues its 16 loads back to back sits on a full TA address FIFO for ~1000 cycles when HBM
 // is near saturation (SQ_VMEM_TA_ADDR_FIFO_FULL), and being in-order it cannot compute meanwhile.
-template <int R3, bool NT>
+template <int R3, bool NT, bool SC = false>
 struct SpreadLoads {
   cx (&nx)[16];
   __amdgpu_buffer_rsrc_t rsrc;
@@ -430,7 +458,7 @@ struct SpreadLoads {
     if (pass > 1 || (half && pass != 0)) return;
     const int idx = pass * 8 + k;
     __builtin_amdgcn_sched_barrier(0);
-    nx[idx] = ld_iq<NT>(rsrc, voff, Geo<R3>::T * idx < L ? soff + (unsigned)(Geo<R3>::T * idx * 8) : kOffNowhere);
+    nx[idx] = ld_iq<NT, SC>(rsrc, voff, Geo<R3>::T * idx < L ? soff + (unsigned)(Geo<R3>::T * idx * (SC ? 4 : 8)) : kOffNowhere);
     __builtin_amdgcn_sched_barrier(0);
   }
 };
@@ -442,6 +470,7 @@ struct SpreadLoads {
 template <class C, class Hook = NoHook>
 CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook = Hook()) {
   using m = M<C::PK>;
+  if constexpr (C::SC16) unpack_frame(u);
   if constexpr (!C::FULL) mask_frame<C::R3>(u, c.t, c.L);
   if constexpr (C::WIN && (C::OPT & kHannSym) != 0) {
     dft16_hann<C::PK>(u, v, c.winp, hook);
@@ -666,7 +695,7 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
   if constexpr (SPREAD) {
     static_assert(C::ABL == 0, "ablations use the plain path");
     const int Lrows = C::FULL ? G::N : c.L;
-    const SpreadLoads<C::R3, C::NT> h1{*nx, rsrc, voff, soff_next, 0, HALF, Lrows}, h2{*nx, rsrc, voff, soff_next, 1, HALF, Lrows};
+    const SpreadLoads<C::R3, C::NT, C::SC16> h1{*nx, rsrc, voff, soff_next, 0, HALF, Lrows}, h2{*nx, rsrc, voff, soff_next, 1, HALF, Lrows};
     // Waves in passes 1 and 2 (which also issue the next frame's loads) win VALU arbitration
     // against waves in pass 3 / epoch close: measured +1.4 % (76.9 vs 75.8 %); raising pass 1 alone,
     // pass 3 alone or the LDS phases gains nothing.
@@ -984,7 +1013,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
         }
       }
       if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
-      const float f = __fdiv_rn(sum, Kf);
+      const float f = sc_unscale<C>(__fdiv_rn(sum, Kf));
       const bool in = b < nb;
       if (p.decide == CRN_DECIDE_THRESHOLD_K) {
         const float ref = p.ref_band >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), p.ref_band)) : 1.0f;
@@ -1063,7 +1092,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
     // the first team of the group stores and decides; lane b holds band b (n_bands <= 16)
     if (t < TEAM) {
-      const float f = MAG ? fsum * fsum : __fdiv_rn(fsum, Kf);  // .cpp:194-197
+      const float fs1 = MAG ? sc_unscale<C>(fsum) : fsum;
+      const float f = MAG ? fs1 * fs1 : sc_unscale<C>(__fdiv_rn(fsum, Kf));  // .cpp:194-197
       const int half = TEAM == 32 ? (tid & 32) : 0;             // two groups share a wave at T = 32
       auto from_lane = [&](int b) {
         const float lo_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), b));
@@ -1125,7 +1155,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const float x = spec[spec_phys(t + T * r)];
-        dst[t + T * r] = MAG ? x : __fdiv_rn(x, Kf);
+        dst[t + T * r] = sc_unscale<C>(MAG ? x : __fdiv_rn(x, Kf));
       }
     }
 
@@ -1189,7 +1219,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
         }
         while (k < hi) sum += spec[spec_phys(k++)];
       }
-      featl[b] = MAG ? sum * sum : __fdiv_rn(sum, Kf);  // .cpp:194-197
+      const float msum = MAG ? sc_unscale<C>(sum) : sum;
+      featl[b] = MAG ? msum * msum : sc_unscale<C>(__fdiv_rn(sum, Kf));  // .cpp:194-197
     }
     if constexpr ((C::OPT & kTrace) != 0) tr2 = __builtin_amdgcn_s_memtime();  // LDS form: this wave's band sums done
     if constexpr (G::XWAVE) __syncthreads();
@@ -1244,15 +1275,16 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
 
 // Buffer resource over the IQ window of epoch group `eg` (GROUPS consecutive epochs): anything
 // past the window, or past the end of the batch, reads as zero.
-template <int R3>
+template <int R3, int SB = 8>
 CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg, int span = 1) {
   using G = Geo<R3>;
   const long long first = eg * G::GROUPS * p.epoch_stride;
-  long long left = (p.total_samples - first) * 8;
-  const long long window = ((long long)span * G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * 8;
+  long long left = (p.total_samples - first) * SB;
+  const long long window = ((long long)span * G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * SB;
   if (left > window) left = window;
   if (left < 0) left = 0;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.iq + first), 0, (int)left, 0x00020000);
+  char *base = reinterpret_cast<char *>(const_cast<float2 *>(p.iq)) + first * SB;   // p.iq is int16 pairs when SB == 4
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)left, 0x00020000);
 }
 
 // Epoch groups [g0, g0 + n_local) of a streaming workgroup (graded launch: launch_cfg).
@@ -1279,7 +1311,8 @@ CRN_DEV StreamSpan stream_span(const SenseParams &p) {
 template <class C>
 __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p) {
   constexpr int R3 = C::R3, NBUF = C::NBUF;
-  constexpr bool NT = C::NT;
+  constexpr bool NT = C::NT, SC = C::SC16;
+  constexpr unsigned SB = C::SB;
   using G = Geo<R3>;
   constexpr int T = G::T;
   extern __shared__ __attribute__((aligned(16))) cx lds[];
@@ -1335,8 +1368,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
 
   constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
-  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * 8u;
-  const unsigned fbytes = (unsigned)p.frame_stride * 8u;
+  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * SB;
+  const unsigned fbytes = (unsigned)p.frame_stride * SB;
 
   cx ua[16], ub[16];
   [[maybe_unused]] cx u0[16];
@@ -1352,12 +1385,12 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       // lane groups in runs of epw (group g: epochs E0 + g epw ...), so that each group's stream is
       // contiguous; every group runs epw x K frames (the ragged end closes inactive epochs: uniform
       // barriers, loads past the batch return zero).
-      constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
+      constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
       const StreamSpan sp = stream_span<R3>(p);
-      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, sp.g0, sp.epw);
-      const unsigned voff = (unsigned)(grp * sp.epw * (unsigned)p.epoch_stride + t) * 8u;  // shadows the per-epoch one
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, sp.g0, sp.epw);
+      const unsigned voff = (unsigned)(grp * sp.epw * (unsigned)p.epoch_stride + t) * SB;  // shadows the per-epoch one
       c.grp_epoch_stride = sp.epw;
-      load_frame<R3, NT>(ua, rs, voff, 0u);
+      load_frame<R3, NT, SC>(ua, rs, voff, 0u);
       // Three half-frame sets whose roles rotate (current low half, current high half, incoming):
       // the loop is unrolled by three so the rotation is a renaming, not 16 register moves a frame.
       cx ha[16], hb[16], hc[16];  // only [0, 8) of each is used (frame_compute's prefetch target is a cx[16])
@@ -1395,8 +1428,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   }
   {
     const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
-    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3>(p, blockIdx.x);
-    load_frame<R3, NT>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3, (int)SB>(p, blockIdx.x);
+    load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
     if constexpr (C::ABL >= 2) {
 #pragma unroll
       for (int r = 0; r < 16; r++) u0[r] = ua[r];
@@ -1407,7 +1440,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
         // Three half-frame register sets: two hold the current frame's raw samples, the third
         // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
         // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
-        constexpr unsigned hbytes = (unsigned)(G::N / 2) * 8u;
+        constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
         cx h0[8], h1[8], hn[16];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -1435,19 +1468,19 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     if constexpr ((C::OPT & kPair) != 0 && C::ABL == 0 && C::NBUF == 2) {
       // Frame pairs, two pairs per iteration in ping-pong: (ua, ub) and (uc, ud).
       cx uc[16], ud[16];
-      load_frame<R3, NT>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
+      load_frame<R3, NT, SC>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
       int f = 0;
       for (; f + 3 < K; f += 4) {
-        load_frame<R3, NT>(uc, rsrc, voff, (unsigned)(f + 2) * fbytes);
-        load_frame<R3, NT>(ud, rsrc, voff, (unsigned)(f + 3) * fbytes);
+        load_frame<R3, NT, SC>(uc, rsrc, voff, (unsigned)(f + 2) * fbytes);
+        load_frame<R3, NT, SC>(ud, rsrc, voff, (unsigned)(f + 3) * fbytes);
         frame_pair_compute<C>(ua, ub, c);
-        load_frame<R3, NT>(ua, rsrc, voff, f + 4 < K ? (unsigned)(f + 4) * fbytes : kNowhere);
-        load_frame<R3, NT>(ub, rsrc, voff, f + 5 < K ? (unsigned)(f + 5) * fbytes : kNowhere);
+        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 4 < K ? (unsigned)(f + 4) * fbytes : kNowhere);
+        load_frame<R3, NT, SC>(ub, rsrc, voff, f + 5 < K ? (unsigned)(f + 5) * fbytes : kNowhere);
         frame_pair_compute<C>(uc, ud, c);
       }
       const int rem = K - f;  // 0..3 frames left, the first two of them already in (ua, ub)
       if (rem >= 2) {
-        load_frame<R3, NT>(uc, rsrc, voff, rem == 3 ? (unsigned)(f + 2) * fbytes : kNowhere);
+        load_frame<R3, NT, SC>(uc, rsrc, voff, rem == 3 ? (unsigned)(f + 2) * fbytes : kNowhere);
         frame_pair_compute<C>(ua, ub, c);
         if (rem == 3) {
           group_sync<C>();
@@ -1484,9 +1517,9 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       const StreamSpan sp = stream_span<R3>(p);
       const int epw = sp.epw, n_local = sp.n_local;
       const long long g0 = sp.g0;
-      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3>(p, g0, epw);
-      const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * 8u;
-      load_frame<R3, NT>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
+      const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
+      load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
       int j = 0, f = 0;
 #define CRN_STREAM_STEP(CUR, NXT)                                                                   \
       {                                                                                             \
@@ -1516,9 +1549,9 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       // last frame they point outside the window and fetch nothing.
       int f = 0;
       for (; f + 1 < K; f += 2) {
-        load_frame<R3, NT>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+        load_frame<R3, NT, SC>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
         frame_step<C>(ua, c, f, u0);
-        load_frame<R3, NT>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
         frame_step<C>(ub, c, f + 1, u0);
       }
       if (f < K) frame_step<C>(ua, c, f, u0);
@@ -1526,7 +1559,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       for (int f = 0; f < K; f++) {
         frame_step<C>(ua, c, f, u0);
         if constexpr (C::ABL < 2)
-          load_frame<R3, NT>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
+          load_frame<R3, NT, SC>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
       }
     }
     epoch_close<C>(c, p, epoch_base);
@@ -1718,8 +1751,41 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   return hipErrorInvalidValue;
 }
 
+// Wire-format input (kSc16): the default kernels of every size and mode, the plain 4096-point kernel's three forms, and the
+// Welch configuration (periodic Hann, whole frames, energy).  Other windowed combinations are not compiled in wire format.
+template <int R3>
+static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
+  constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
+  if (win) {
+    if (mag || !p.hann_sym || p.L != Geo<R3>::N) return hipErrorNotSupported;
+    if constexpr (R3 == 16) {
+      if (p.aligned_shift != 0)
+        return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);
+    }
+    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
+  }
+  if constexpr (R3 == 16) {
+    if (!mag && p.L == Geo<R3>::N) {
+      if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRows | kRegBands>(p, mag, win, stream);
+      if (reg_bands(p)) return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRegBands>(p, mag, win, stream);
+      return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C>(p, mag, win, stream);
+    }
+  }
+  return launch_default<R3, 1, true, true, false, 3, true, kBase, 1>(p, mag, win, stream);
+}
+
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool sc16) {
+  if (sc16) {
+    switch (fft_len) {
+      case 512: return launch_r_sc16<2>(p, mag, win, stream);
+      case 1024: return launch_r_sc16<4>(p, mag, win, stream);
+      case 2048: return launch_r_sc16<8>(p, mag, win, stream);
+      case 4096: return launch_r_sc16<16>(p, mag, win, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (fft_len) {
     case 512: return launch_r<2>(p, mag, win, variant, stream);
     case 1024: return launch_r<4>(p, mag, win, variant, stream);
@@ -2029,6 +2095,24 @@ hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream) {
   if (p.n_epochs <= 0 || p.epochs_per_stream <= 0) return hipSuccess;
   const long long n_streams = p.n_epochs / p.epochs_per_stream;
   hipLaunchKernelGGL(pu_pattern_kernel, dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+// complex floats -> the radio's wire format (int16 pairs, full scale 32768): crn_pack_sc16_device
+__global__ __launch_bounds__(256) void pack_sc16_kernel(const float2 *iq, long long n, short2 *out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float2 v = iq[i];
+    out[i] = make_short2((short)fminf(fmaxf(rintf(v.x * 32768.f), -32768.f), 32767.f), (short)fminf(fmaxf(rintf(v.y * 32768.f), -32768.f), 32767.f));
+  }
+}
+
+hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, hipStream_t stream) {
+  if (n_samples <= 0) return hipSuccess;
+  long long blocks = (n_samples + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(pack_sc16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float2 *>(iq), n_samples,
+                     reinterpret_cast<short2 *>(out));
   return hipGetLastError();
 }
 

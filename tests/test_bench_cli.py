@@ -47,7 +47,9 @@ def test_bench_default_batch_with_every_alt_leg_and_the_cpu_check(built):
     samples) — and the CPU sample check after them still reads the headline launch's results, not a leg's."""
     d = _run("--cpu-epochs", "64", epochs=())
     alt = d["config"]["alt"]
-    assert set(alt) == {"cfgH_2GiB_batch", "unpruned", "adc16_input"}
+    assert set(alt) == {"cfgH_2GiB_batch", "unpruned", "adc16_input", "wire_format_sc16"}
+    assert alt["wire_format_sc16"]["bytes_per_step"] * 2 == alt["adc16_input"]["bytes_per_step"]
+    assert alt["wire_format_sc16"]["Msamples/s"] > alt["adc16_input"]["Msamples/s"]
     for leg in alt.values():
         assert 0.3 < leg["frac"] < 1.0 and leg["kernel_ms_mean"] > 0
     assert alt["cfgH_2GiB_batch"]["bytes_per_step"] == 6553 * 40960 * 8
@@ -99,3 +101,13 @@ def test_bench_falls_back_to_torch_rccl_when_the_c_abi_cannot_load_rccl(built):
     ex.finish(stream)
     torch.cuda.synchronize()
     assert (ex.gathered_host(2) == 3).all()
+
+
+def test_bench_wire_format_mode(built):
+    """--wire-format: samples held as int16 pairs; the oracle check of the run still applies (it compares against the float samples the
+    wire buffer was packed from), bytes per step are 4 per sample, and the workload says it is not the headline configuration."""
+    d = _run("--cpu-epochs", "0", "--wire-format")
+    assert d["config"]["bytes_per_gpu_per_step"] == 512 * 40960 * 4
+    assert "NOT THE HEADLINE CONFIGURATION" in d["config"]["workload"] and d["roofline"]["traffic"] is None
+    d = _run("--cpu-epochs", "0", "--wire-format", "--mode", "welch")
+    assert "wire format" in d["config"]["workload"]

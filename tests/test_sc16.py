@@ -1,0 +1,99 @@
+"""Samples kept in the radio's wire format (crn_sense_run_device_sc16: int16 pairs, 4 bytes per complex sample — what the reference's
+USRPs put on the network, src/extensible_cognitive_radio.cpp:1263-1265): the kernel converts in its first pass exactly as UHD's
+converter does (int16 / 32768), so every output must be BIT-IDENTICAL to the float path on the converted samples — and through it
+equal to the oracle within the float path's own tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import crnsense as cs
+import oracle_py as orc
+
+
+def test_sc16_argument_errors(built):
+    L = cs.lib()
+    o = cs.Out()
+    assert L.crn_sense_run_device_sc16(None, None, 1, 512, 0, C.byref(o), None) == cs.CRN_ERR_ARG
+    assert L.crn_pack_sc16_device(None, None, 1, None, None) == cs.CRN_ERR_ARG
+
+
+def _cfgs():
+    yield "ref512", cs.cfg_reference(), 512
+    yield "ref512_L364", cs.cfg_reference(), 364
+    yield "ref512_L1", cs.cfg_reference(), 1
+    for n in (512, 1024, 2048, 4096):
+        yield f"energy{n}", cs.cfg_energy_scaled(n, 4.0), n
+    yield "energy4096_L3000", cs.cfg_energy_scaled(4096, 4.0), 3000
+    c = cs.cfg_energy_scaled(4096, 4.0)          # a band outside the reference plan's rows: the unpruned 4096-point kernel
+    c.segs[2].lo, c.segs[2].hi = 900, 1100
+    yield "energy4096_other_plan", c, 4096
+    c = cs.cfg_energy_scaled(1024, 4.0)
+    c.mode = cs.MODE_REF_MAG
+    yield "mag1024", c, 1024
+    for n in (1024, 4096):
+        yield f"welch{n}", cs.cfg_welch(n, 8, 64), n
+    c = cs.cfg_welch(4096, 5, 16)               # 256-bin aligned bands
+    yield "welch4096_16bands", c, 4096
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,L", list(_cfgs()), ids=[n for n, _, _ in _cfgs()])
+@pytest.mark.parametrize("want_spectrum", [False, True], ids=["", "spectrum"])
+def test_wire_format_is_bit_identical_to_the_float_path(built, name, cfg, L, want_spectrum):
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 37
+    spe = cs.samples_per_epoch(cfg, L)
+    need = cs.samples_needed(cfg, n, L)
+    rng = np.random.default_rng(abs(hash(name)) % 2 ** 31)
+    raw = rng.integers(-2000, 2000, (need, 2), dtype=np.int16)
+    raw[rng.random(need) < 0.01] = rng.integers(-32768, 32767, 2, dtype=np.int16)        # full-scale excursions, both extremes
+    raw[0], raw[1] = (-32768, 32767), (32767, -32768)
+    host_f = (raw.astype(np.float32) / np.float32(32768.0)).ravel()                       # UHD's sc16 -> fc32 conversion
+    d_raw = torch.from_numpy(raw.copy()).to(dev)
+    d_f = torch.from_numpy(host_f).to(dev)
+    s = cs.Sensor(cfg)
+    for k in range(cfg.n_bands):
+        if np.isfinite(cfg.thresh[k]) and cfg.ref_band < 0:
+            cfg.thresh[k] = 1e-3
+    outs = []
+    for _ in range(2):
+        feats = torch.zeros(n, cfg.n_bands, device=dev)
+        ann = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+        dec = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        occ = torch.full((n, cfg.n_bands), 9, dtype=torch.uint8, device=dev)
+        spec = torch.zeros(n, cfg.fft_len, device=dev) if want_spectrum else None
+        outs.append((feats, ann, dec, occ, spec))
+    ptrs = [{"features": o[0].data_ptr(), "ann_out": o[1].data_ptr(), "decision": o[2].data_ptr(), "occupancy": o[3].data_ptr(),
+             "spectrum": o[4].data_ptr() if want_spectrum else 0} for o in outs]
+    s.run_device(d_f.data_ptr(), n, L, ptrs[0])
+    s.run_device(d_raw.data_ptr(), n, L, ptrs[1], sc16=True)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        if a is not None:
+            assert torch.equal(a, b)                                                      # bit for bit
+    want = orc.run(cfg, host_f, n, L=L)
+    assert np.allclose(outs[1][0].cpu().numpy(), want["features"], rtol=3e-5, atol=0)
+    # the device packer inverts the conversion exactly
+    packed = torch.zeros(need, 2, dtype=torch.int16, device=dev)
+    s.pack_sc16_device(d_f.data_ptr(), need, packed.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(packed, d_raw)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_wire_format_refuses_what_is_not_compiled(built):
+    import torch
+    cfg = cs.cfg_welch(1024, 8, 64)
+    cfg.window = cs.WINDOW_BLACKMAN_HARRIS
+    s = cs.Sensor(cfg)
+    x = torch.zeros(cs.samples_needed(cfg, 4), 2, dtype=torch.int16, device="cuda")
+    f = torch.zeros(4, 64, device="cuda")
+    with pytest.raises(cs.CrnError) as ei:
+        s.run_device(x.data_ptr(), 4, 1024, {"features": f.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0}, sc16=True)
+    assert "wire-format" in str(ei.value)
+    with pytest.raises(cs.CrnError):
+        s.run_device(x.data_ptr() + 2, 4, 1024, {"features": f.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0}, sc16=True)
+    s.close()
