@@ -235,6 +235,12 @@ typedef struct crn_epoch_result {
  * ring will ever use is allocated by this call. */
 CRN_API int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet,
                               int32_t epochs_per_batch, crn_ingest **out);
+/* The same ring for packets in the radio's wire format (int16 pairs, 4 bytes per complex sample: crn_sense_run_device_sc16): half
+ * the bytes through the pushing thread's copy, the bus and HBM.  Packets go in through crn_ingest_push_sc16 (CRN_ERR_STATE for the
+ * other kind of push); everything else is shared. */
+CRN_API int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
+                                   crn_ingest **out);
+CRN_API int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet);
 /* Packets of a different length (<= the creation length) from now on: the rx worker learns the UHD
  * packet size only when it starts (src/extensible_cognitive_radio.cpp:1263-1265), after the engine
  * was constructed.  CRN_ERR_STATE while epochs are staged. */

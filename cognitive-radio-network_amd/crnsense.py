@@ -29,7 +29,7 @@ EXPORTS = [
     "crn_sense_run_device_sc16", "crn_pack_sc16_device",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant",
-    "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
+    "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
     "crn_noise_floor_device", "crn_sense_set_thresholds",
     "crn_sense_reserve_host", "crn_sense_set_timing", "crn_sense_get_stats", "crn_ingest_get_stats",
@@ -145,6 +145,8 @@ def lib():
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
         L.crn_ingest_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.crn_ingest_push.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.crn_ingest_create_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.crn_ingest_push_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.crn_ingest_flush.argtypes = [C.c_void_p]
         L.crn_ingest_poll.argtypes = [C.c_void_p, C.POINTER(EpochResult), C.c_int32, C.POINTER(C.c_int32)]
         L.crn_ingest_drain.argtypes = [C.c_void_p]
@@ -400,19 +402,21 @@ class Comm:
 class Ingest:
     """Packet ingest ring over a Sensor (crn_ingest_* in include/crn_sense.h)."""
 
-    def __init__(self, sensor, n_streams, samples_per_packet, epochs_per_batch):
+    def __init__(self, sensor, n_streams, samples_per_packet, epochs_per_batch, sc16=False):
+        """sc16: packets are int16 pairs (the radio's wire format) instead of complex floats."""
         self.sensor = sensor
         self._g = C.c_void_p()
-        check(lib().crn_ingest_create(sensor._h, n_streams, samples_per_packet, epochs_per_batch,
-                                      C.byref(self._g)), "crn_ingest_create")
+        self._push = lib().crn_ingest_push_sc16 if sc16 else lib().crn_ingest_push
+        create = lib().crn_ingest_create_sc16 if sc16 else lib().crn_ingest_create
+        check(create(sensor._h, n_streams, samples_per_packet, epochs_per_batch, C.byref(self._g)), "crn_ingest_create")
 
     def push(self, stream, packet, block=True):
         """block=True: on CRN_ERR_BUSY wait for a free buffer and push again (tests, tools);
         block=False: returns False when the packet was refused (what an engine's execute() does)."""
-        rc = lib().crn_ingest_push(self._g, stream, packet.ctypes.data)
+        rc = self._push(self._g, stream, packet.ctypes.data)
         while rc == CRN_ERR_BUSY and block:
             check(lib().crn_ingest_wait(self._g), "crn_ingest_wait")
-            rc = lib().crn_ingest_push(self._g, stream, packet.ctypes.data)
+            rc = self._push(self._g, stream, packet.ctypes.data)
         if rc == CRN_ERR_BUSY:
             return False
         check(rc, "crn_ingest_push")

@@ -48,8 +48,8 @@ struct Slot {
 enum : int { kFree = 0, kQueued = 1 };  // Batch::state: owned by the caller / by the launcher thread
 
 struct Batch {
-  float *h_iq = nullptr;        // pinned [C][K][cap] interleaved
-  float *d_iq = nullptr;
+  char *h_iq = nullptr;         // pinned [C][K][cap] samples (complex floats, or int16 pairs in a wire-format ring)
+  char *d_iq = nullptr;
   char *h_res = nullptr;        // pinned results: features | ann | decision | occupancy
   char *d_res = nullptr;
   hipEvent_t done = nullptr;
@@ -68,7 +68,8 @@ struct crn_ingest {
   crn_handle *h = nullptr;
   crn_cfg cfg;
   int n_streams = 0, L = 0, cap = 0, B = 0, C = 0, K = 0;
-  size_t epoch_floats = 0;                 // K * L * 2 (dense: the kernel is run with samples_per_frame = L)
+  size_t sample_bytes = 8;                 // 8: complex floats; 4: the radio's wire format (crn_ingest_create_sc16)
+  size_t epoch_bytes = 0;                  // K * L * sample_bytes (dense: the kernel is run with samples_per_frame = L)
   size_t off_ann = 0, off_dec = 0, off_occ = 0, res_bytes = 0;
   hipStream_t stream = nullptr;
   Batch batch[2];
@@ -106,8 +107,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // H2D + kernel + D2H + event for one batch; returns an error message or "".
 std::string enqueue(crn_ingest *g, Batch &b) {
-  const size_t epoch_floats = (size_t)g->K * b.L * 2;
-  const size_t in_bytes = (size_t)b.launched * epoch_floats * sizeof(float);
+  const size_t in_bytes = (size_t)b.launched * (size_t)g->K * b.L * g->sample_bytes;
   // a small batch (the engine's one epoch): the kernel reads the pinned slots and writes the pinned results over the bus itself —
   // one launch instead of upload + launch + download: the kernel takes 30 instead of 23 us for one reference epoch, the results
   // are readable 15-19 us sooner (tools/ring_rate: 89 -> 74 us; 8 epochs: 92 -> 73 us).  $CRN_INGEST_ZEROCOPY_BYTES: largest
@@ -123,7 +123,11 @@ std::string enqueue(crn_ingest *g, Batch &b) {
   out.decision = reinterpret_cast<int32_t *>(res + g->off_dec);
   out.occupancy = reinterpret_cast<uint8_t *>(res + g->off_occ);
   out.spectrum = nullptr;
-  if (crn_sense_run_device(g->h, zero_copy ? b.h_iq : b.d_iq, b.launched, b.L, 0, &out, g->stream) != CRN_OK) return crn_last_error();
+  const void *src = zero_copy ? b.h_iq : b.d_iq;
+  const int rc = g->sample_bytes == 4
+                     ? crn_sense_run_device_sc16(g->h, static_cast<const int16_t *>(src), b.launched, b.L, 0, &out, g->stream)
+                     : crn_sense_run_device(g->h, static_cast<const float *>(src), b.launched, b.L, 0, &out, g->stream);
+  if (rc != CRN_OK) return crn_last_error();
   if (!zero_copy) e = hipMemcpyAsync(b.h_res, b.d_res, g->res_bytes, hipMemcpyDeviceToHost, g->stream);
   if (e == hipSuccess) e = hipEventRecord(b.done, g->stream);
   if (e != hipSuccess) return std::string("hipMemcpyAsync(D2H) / hipEventRecord: ") + hipGetErrorString(e);
@@ -261,8 +265,7 @@ int launch(crn_ingest *g) {
       if (sl.stream < 0 || sl.npk == g->K) continue;
       const int j = o.assigned++;
       o.slots[j] = sl;
-      std::memcpy(o.h_iq + (size_t)j * g->epoch_floats, b.h_iq + (size_t)i * g->epoch_floats,
-                  (size_t)sl.npk * g->L * 2 * sizeof(float));
+      std::memcpy(o.h_iq + (size_t)j * g->epoch_bytes, b.h_iq + (size_t)i * g->epoch_bytes, (size_t)sl.npk * g->L * g->sample_bytes);
       g->open_slot[sl.stream] = j;
       sl.stream = -1;
     }
@@ -294,8 +297,8 @@ void wait_free(crn_ingest *g, Batch &b) {
 
 extern "C" {
 
-int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
-                      crn_ingest **out) {
+static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
+                         crn_ingest **out, size_t sample_bytes) {
   if (!h || !out) return crn::fail(CRN_ERR_ARG, "crn_ingest_create: null argument");
   *out = nullptr;
   crn_cfg cfg;
@@ -315,7 +318,8 @@ int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_pack
   // every stream can have one epoch open: with C >= n_streams a full buffer always holds a complete one
   g->C = epochs_per_batch > n_streams ? epochs_per_batch : n_streams;
   g->K = cfg.frames_per_epoch;
-  g->epoch_floats = (size_t)g->K * g->L * 2;
+  g->sample_bytes = sample_bytes;
+  g->epoch_bytes = (size_t)g->K * g->L * sample_bytes;
   const size_t nb = (size_t)cfg.n_bands;
   g->off_ann = align_up((size_t)g->C * nb * sizeof(float), 256);
   g->off_dec = g->off_ann + align_up((size_t)g->C * 3 * sizeof(double), 256);
@@ -327,7 +331,7 @@ int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_pack
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     Batch &b = g->batch[i];
     b.slots.resize(g->C);
-    const size_t iq_bytes = (size_t)g->C * g->epoch_floats * sizeof(float);
+    const size_t iq_bytes = (size_t)g->C * g->epoch_bytes;
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_iq), iq_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.d_iq), iq_bytes);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_res), g->res_bytes, hipHostMallocDefault);
@@ -354,12 +358,15 @@ int crn_ingest_set_packet_len(crn_ingest *g, int32_t samples_per_packet) {
   if (!is_free(b)) return crn::fail(CRN_ERR_BUSY, "ingest ring: both batch buffers are in flight");
   if (b.assigned != 0) return crn::fail(CRN_ERR_STATE, "crn_ingest_set_packet_len: epochs are staged (flush first)");
   g->L = samples_per_packet;
-  g->epoch_floats = (size_t)g->K * g->L * 2;
+  g->epoch_bytes = (size_t)g->K * g->L * g->sample_bytes;
   return CRN_OK;
 }
 
-int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) {
+static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, size_t sample_bytes) {
   if (!g || !iq_packet) return crn::fail(CRN_ERR_ARG, "crn_ingest_push: null argument");
+  if (sample_bytes != g->sample_bytes)
+    return crn::fail(CRN_ERR_STATE, g->sample_bytes == 4 ? "this ring takes wire-format packets: crn_ingest_push_sc16"
+                                                          : "this ring takes complex-float packets: crn_ingest_push");
   if (stream < 0 || stream >= g->n_streams) return crn::fail(CRN_ERR_ARG, "stream id out of range");
   for (int attempt = 0;; attempt++) {
     Batch &b = g->batch[g->fill];
@@ -382,8 +389,7 @@ int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) {
       g->open_slot[stream] = sl;
     }
     Slot &s = b.slots[sl];
-    std::memcpy(b.h_iq + (size_t)sl * g->epoch_floats + (size_t)s.npk * g->L * 2, iq_packet,
-                (size_t)g->L * 2 * sizeof(float));
+    std::memcpy(b.h_iq + (size_t)sl * g->epoch_bytes + (size_t)s.npk * g->L * g->sample_bytes, iq_packet, (size_t)g->L * g->sample_bytes);
     g->packets++;
     if (++s.npk < g->K) return CRN_OK;
     g->open_slot[stream] = -1;
@@ -395,6 +401,15 @@ int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) {
     return CRN_OK;
   }
 }
+
+int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch, crn_ingest **out) {
+  return ingest_create(h, n_streams, samples_per_packet, epochs_per_batch, out, 8);
+}
+int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch, crn_ingest **out) {
+  return ingest_create(h, n_streams, samples_per_packet, epochs_per_batch, out, 4);
+}
+int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) { return ingest_push(g, stream, iq_packet, 8); }
+int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet) { return ingest_push(g, stream, iq_packet, 4); }
 
 int crn_ingest_flush(crn_ingest *g) {
   if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");

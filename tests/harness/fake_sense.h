@@ -45,6 +45,26 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   }
   return CRN_OK;
 }
+// wire-format twin of the stand-in: the same "features" from int16 pairs
+int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o, void *) {
+  if (g_fail_next_launch.exchange(0)) return crn::fail(CRN_ERR_DEVICE, "forced launch failure");
+  const int K = h->cfg.frames_per_epoch, nb = h->cfg.n_bands;
+  for (int64_t e = 0; e < n_epochs; e++) {
+    const int16_t *x = d_iq + (size_t)e * K * L * 2;
+    double s = 0;
+    for (int i = 0; i < K * L * 2; i++) s += x[i];
+    if (o->features) {
+      for (int b = 0; b < nb; b++) o->features[e * nb + b] = 0.f;
+      o->features[e * nb + 0] = (float)s;
+      o->features[e * nb + 1] = (float)x[0];
+    }
+    if (o->decision) o->decision[e] = -L;   // negative: the wire-format launch ran
+    if (o->ann_out)
+      for (int k = 0; k < 3; k++) o->ann_out[e * 3 + k] = (double)k;
+    if (o->occupancy) memset(o->occupancy + e * nb, 0, (size_t)nb);
+  }
+  return CRN_OK;
+}
 }
 
 #endif

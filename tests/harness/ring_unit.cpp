@@ -233,6 +233,37 @@ int main() {
     REQUIRE(st.packets == 20 && st.batches == 1 && st.batches_failed == 1 && st.epochs_launched == 1 && st.epochs_ready == 1);
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
+  // 7. a wire-format ring: int16 packets, the wire-format launch, the other kind of push refused
+  {
+    REQUIRE(crn_ingest_create_sc16(&h, 2, 100, 2, &g) == CRN_OK);
+    std::vector<float> fpk(200, 1.f);
+    REQUIRE(crn_ingest_push(g, 0, fpk.data()) == CRN_ERR_STATE);
+    std::vector<crn_epoch_result> all;
+    long want[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    for (int e = 0; e < 3; e++)
+      for (int p = 0; p < 10; p++)
+        for (int st = 0; st < 2; st++) {
+          std::vector<int16_t> pk(200);
+          for (int i = 0; i < 200; i++) pk[i] = (int16_t)((st * 7919 + e * 131 + p * 17 + i * 3) % 2001 - 1000);
+          for (int i = 0; i < 200; i++) want[st][e] += pk[i];
+          int rc;
+          while ((rc = crn_ingest_push_sc16(g, st, pk.data())) == CRN_ERR_BUSY) REQUIRE(crn_ingest_wait(g) == CRN_OK);
+          REQUIRE(rc == CRN_OK);
+          collect(g, &all);
+        }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    REQUIRE(all.size() == 6);
+    for (const crn_epoch_result &r : all) {
+      REQUIRE(r.decision == -100);                                    // the wire-format launch ran, with L = 100
+      REQUIRE(r.features[0] == (float)want[r.stream][r.epoch_seq]);   // exactly its own ten packets
+    }
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    REQUIRE(crn_ingest_create(&h, 1, 100, 1, &g) == CRN_OK);
+    std::vector<int16_t> ipk(200, 1);
+    REQUIRE(crn_ingest_push_sc16(g, 0, ipk.data()) == CRN_ERR_STATE);
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
   printf("ring_unit: ok\n");
   return 0;
 }

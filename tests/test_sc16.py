@@ -97,3 +97,34 @@ def test_wire_format_refuses_what_is_not_compiled(built):
     with pytest.raises(cs.CrnError):
         s.run_device(x.data_ptr() + 2, 4, 1024, {"features": f.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0}, sc16=True)
     s.close()
+
+
+@pytest.mark.gpu
+def test_wire_format_ring_matches_the_float_ring(built):
+    """The ingest ring fed int16 packets (crn_ingest_create_sc16 / crn_ingest_push_sc16) against the ring fed the same samples as
+    complex floats: the same (stream, epoch) results, bit for bit, reference-sized packets (364 of 512)."""
+    cfg = cs.cfg_reference()
+    rng = np.random.default_rng(77)
+    S, E, L = 3, 6, 364
+    raw = rng.integers(-3000, 3000, (S, E, 10, L, 2), dtype=np.int16)
+    got = {}
+    for sc16 in (False, True):
+        sn = cs.Sensor(cfg)
+        ring = cs.Ingest(sn, S, L, 4, sc16=sc16)
+        res = []
+        for e in range(E):
+            for p in range(10):
+                for st in range(S):
+                    pk = raw[st, e, p] if sc16 else (raw[st, e, p].astype(np.float32) / np.float32(32768.0))
+                    ring.push(st, np.ascontiguousarray(pk))
+            res += ring.poll()
+        ring.drain()
+        res += ring.poll()
+        got[sc16] = {(r.stream, r.epoch_seq): (r.decision, tuple(r.features[:4]), tuple(r.ann_out)) for r in res}
+        assert len(got[sc16]) == S * E
+        if sc16:
+            with pytest.raises(cs.CrnError):
+                cs.check(cs.lib().crn_ingest_push(ring._g, 0, np.zeros(2 * L, np.float32).ctypes.data), "crn_ingest_push")
+        ring.close()
+        sn.close()
+    assert got[True] == got[False]
