@@ -19,7 +19,8 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("power_probe.txt", f"{tag}_power_clock_probe.txt"), ("cpu_scaling.txt", f"{tag}_cpu_thread_scaling.txt"),
                  ("per_bin_error_at_floor.txt", f"{tag}_per_bin_error_at_floor.txt"),
                  ("engine_execute_latency.txt", f"{tag}_engine_execute_latency.txt"),
-                 ("bench_adc16.jsonl", f"{tag}_bench_radio_format_input.jsonl")):
+                 ("bench_adc16.jsonl", f"{tag}_bench_radio_format_input.jsonl"),
+                 ("bench_wire_format.jsonl", f"{tag}_bench_wire_format_sc16.jsonl"), ("ring_rate.txt", f"{tag}_ring_rate_round.txt")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
         shutil.copy(m[-1], os.path.join(DST, dst))

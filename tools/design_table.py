@@ -32,6 +32,8 @@ rows.append(alt_row("same batch, no row pruning (`config.alt.unpruned`: any othe
 rows.append(alt_row("same kernel, SURVEY.md §8(d)'s 2 GiB batch (`config.alt.cfgH_2GiB_batch`, 6 553 epochs)", h["config"]["alt"]["cfgH_2GiB_batch"]))
 if "adc16_input" in h["config"]["alt"]:
     rows.append(alt_row("same batch and kernel, every sample rounded to the USRP's 16-bit wire format (`config.alt.adc16_input`: what the reference's radios deliver; §8)", h["config"]["alt"]["adc16_input"]))
+if "wire_format_sc16" in h["config"]["alt"]:
+    rows.append(alt_row("**not the headline configuration**: the same samples held in HBM in the radio's wire format, int16 pairs = 4 B per sample (`config.alt.wire_format_sc16`, `crn_sense_run_device_sc16`; outputs bit-identical; GB/s and % are of the 4 B per sample actually read — the kernel is bound by the vector unit at the power cap, §5)", h["config"]["alt"]["wire_format_sc16"]))
 rows.append(row("same batch, epoch close reduced to an accumulator reset (`--variant 16`, ablation: not a sensing result)", load("ablation_no_epoch_close")))
 rows.append(row("cfg1: 1024-pt energy, 114 688 epochs", load("cfg1_1024pt")))
 rows.append(row("2048-pt energy, 57 344 epochs", load("energy_2048pt")))

@@ -20,7 +20,9 @@ timeout 300 python bench.py --fft 512 --cpu-epochs 0 > $O/bench_e512.json 2> $O/
 timeout 300 python bench.py --fft 2048 --cpu-epochs 0 > $O/bench_e2048.json 2> $O/bench_e2048.err
 # the same kernels on samples rounded to the USRP's 16-bit wire format (what the reference's radios deliver): diagnostic lines
 { for m in "--mode welch" "--mode ref" "--fft 1024" "--fft 2048"; do timeout 300 python bench.py $m --adc-bits 16 --cpu-epochs 0 --no-live-traffic --no-alt 2>/dev/null | tail -1; done; } > $O/bench_adc16.jsonl
+{ for m in "" "--fft 1024" "--fft 512" "--fft 2048" "--mode ref" "--mode welch"; do timeout 300 python bench.py $m --wire-format --cpu-epochs 0 2>/dev/null | tail -1; done; } > $O/bench_wire_format.jsonl
 timeout 120 tools/ring_rate 64 256 3 > $O/ring_rate.txt 2>&1; timeout 60 tools/ring_rate 1 1 3 >> $O/ring_rate.txt 2>&1
+timeout 120 tools/ring_rate 64 256 3 sc16 >> $O/ring_rate.txt 2>&1
 ./tools/membw_policy > $O/membw_policy.txt 2>&1
 timeout 300 python tools/host_rate.py > $O/host_rate.txt 2>&1
 timeout 300 python tools/engine_rate.py > $O/engine_rate.txt 2>&1
