@@ -1754,7 +1754,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
 // Wire-format input (kSc16): the default kernels of every size and mode, the plain 4096-point kernel's three forms, and the
 // Welch configuration (periodic Hann, whole frames, energy).  Other windowed combinations are not compiled in wire format.
 template <int R3>
-static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
+static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
   if (win) {
     if (mag || !p.hann_sym || p.L != Geo<R3>::N) return hipErrorNotSupported;
@@ -1766,6 +1766,11 @@ static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, hipStr
   }
   if constexpr (R3 == 16) {
     if (!mag && p.L == Geo<R3>::N) {
+      if (variant == 23) {  // A/B: every twiddle in registers, 3 workgroups per CU (the float path's variant 23)
+        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+          return launch_rn<R3, 1, true, true, false, 3, 0, true, kBase | kRows | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, false, 3, 0, true, kBase>(p, mag, win, stream);
+      }
       if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRows | kRegBands>(p, mag, win, stream);
       if (reg_bands(p)) return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRegBands>(p, mag, win, stream);
@@ -1779,10 +1784,10 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
                         hipStream_t stream, bool sc16) {
   if (sc16) {
     switch (fft_len) {
-      case 512: return launch_r_sc16<2>(p, mag, win, stream);
-      case 1024: return launch_r_sc16<4>(p, mag, win, stream);
-      case 2048: return launch_r_sc16<8>(p, mag, win, stream);
-      case 4096: return launch_r_sc16<16>(p, mag, win, stream);
+      case 512: return launch_r_sc16<2>(p, mag, win, variant, stream);
+      case 1024: return launch_r_sc16<4>(p, mag, win, variant, stream);
+      case 2048: return launch_r_sc16<8>(p, mag, win, variant, stream);
+      case 4096: return launch_r_sc16<16>(p, mag, win, variant, stream);
       default: return hipErrorInvalidValue;
     }
   }

@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd"), os.path.join(ROOT, "tests")]  # run as: python tests/soak_gpu.py [n]
+import torch
 import crnsense as cs, oracle_py as orc, signals
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -76,9 +77,35 @@ for seed in range(n_seeds):
         eg = (np.abs(got["spectrum"] - truth) / np.maximum(truth, fl)).max()
         eo = (np.abs(want["spectrum"] - truth) / np.maximum(truth, fl)).max()
         ok = ok and (eg < 2 * eo + 2e-6 if stride == 0 else eg < 3e-5)  # strided: truth is the fp32 oracle itself
+    # wire format (int16 pairs) against the float path on the converted samples: bit for bit, where it is compiled
+    wire_ok = cfg.window == 0 or (cfg.window == 1 and cfg.mode == 1 and L == n)
+    if ok and wire_ok and variant == 0 and rng.random() < 0.3:
+        raw = np.clip(np.round(iq * 32768.0 * 40.0), -32768, 32767).astype(np.int16)      # x 40: a few hundred levels of noise
+        fl = raw.astype(np.float32) / np.float32(32768.0)
+        d_raw, d_fl = torch.from_numpy(raw).cuda(), torch.from_numpy(fl).cuda()
+        outs2 = []
+        for sc in (False, True):
+            f_ = torch.zeros(n_epochs, cfg.n_bands, device="cuda")
+            o_ = torch.zeros(n_epochs, cfg.n_bands, dtype=torch.uint8, device="cuda")
+            d_ = torch.zeros(n_epochs, dtype=torch.int32, device="cuda")
+            a_ = torch.zeros(n_epochs, 3, dtype=torch.float64, device="cuda")
+            sp_ = torch.zeros(n_epochs, n, device="cuda") if want_spec else None
+            s2 = cs.Sensor(cfg)
+            if epw:
+                s2.set_variant(100 + epw)
+            if tail >= 0:
+                s2.set_variant(200 + tail)
+            s2.run_device((d_raw if sc else d_fl).data_ptr(), n_epochs, L,
+                          {"features": f_.data_ptr(), "ann_out": a_.data_ptr(), "decision": d_.data_ptr(), "occupancy": o_.data_ptr(),
+                           "spectrum": sp_.data_ptr() if want_spec else 0}, epoch_stride=stride, sc16=sc)
+            torch.cuda.synchronize()
+            s2.close()
+            outs2.append((f_, o_, d_, a_, sp_))
+        ok = all(torch.equal(x, y) for x, y in zip(outs2[0], outs2[1]) if x is not None)
+        n_wire = globals().get("n_wire", 0) + 1
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, dict(n=n, mode=cfg.mode, K=cfg.frames_per_epoch, win=cfg.window, L=L, variant=variant,
                                          spec=want_spec, epochs=n_epochs, ref_plan=ref_plan, welch=welch, aligned=aligned, nb=cfg.n_bands, decide=cfg.decide, epw=epw, tail=tail, stride=stride))
-print(f"soak: {n_seeds} configurations, {bad} mismatches")
+print(f"soak: {n_seeds} configurations ({globals().get('n_wire', 0)} of them also through the wire-format path, compared bit for bit), {bad} mismatches")
 sys.exit(1 if bad else 0)
