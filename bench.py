@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--wire-format", action="store_true",
                     help="keep the samples in HBM in the radio's wire format (int16 pairs, 4 bytes per complex sample: "
                          "crn_sense_run_device_sc16) instead of complex floats; implies --adc-bits 16.  Not the headline configuration")
+    ap.add_argument("--uhd-scale", action="store_true",
+                    help="with --adc-bits 16: scale the integer samples by 1/32767 (the constant UHD's sc16 -> fc32 converter uses) instead "
+                         "of the power of two 1/32768: the mantissas fill up (diagnostic)")
     ap.add_argument("--adc-bits", type=int, default=0,
                     help="round every input sample to this many bits (16 = the USRP wire format the reference's radios deliver); "
                          "0 = full-precision fp32 (the default: SURVEY.md §8(d)'s generator, the worst case for power)")
@@ -253,6 +256,9 @@ def main():
         sensor.synth_fill_device_ex(iq.data_ptr(), E, spe, sc0, truth_ptr=truth.data_ptr(), stream=stream)
         if args.adc_bits:
             workload += f" [DIAGNOSTIC INPUT: samples rounded to {args.adc_bits} bits, as a radio delivers them]"
+            if args.uhd_scale and not args.wire_format:
+                iq.mul_(32768.0 / 32767.0)
+                workload += " [scaled by 1/32767 instead of 1/32768]"
     src, sample_bytes = iq, 8
     if args.wire_format and not args.zeros:
         wire = torch.empty(n_samples * 2, dtype=torch.int16, device=dev)
@@ -482,9 +488,11 @@ def main():
                               "kernel_ms_median": float(np.median(ms["adc16"])), "GB/s": frac_of(ms["adc16"]) * HBM_PEAK_GBS,
                               "frac": frac_of(ms["adc16"]), "Msamples/s": E * spe / (float(np.mean(ms["adc16"])) * 1e-3) / 1e6,
                               "frac_fp32_input_interleaved": frac_of(ms["fp32"]), "kernel": info["name"][:40] + "...",
-                              "note": "same batch with every sample rounded to the USRP's 16-bit wire format (crn_synth_cfg.adc_bits = 16): "
-                                      "what the reference's radios deliver; measured in blocks of 10 launches interleaved with the headline's "
-                                      "full-precision fp32 input (frac_fp32_input_interleaved), which is the worst case for power"}
+                              "note": "same batch with every sample rounded to 16 bits on the grid 2^-15 (crn_synth_cfg.adc_bits = 16: the "
+                                      "information a radio's samples carry; a converter constant that is not a power of two, like UHD's "
+                                      "1/32767, fills the mantissas again and keeps about half of the effect: --uhd-scale); measured in blocks "
+                                      "of 10 launches interleaved with the headline's full-precision fp32 input "
+                                      "(frac_fp32_input_interleaved), which is the worst case for power"}
         # ... and held in HBM in that wire format (int16 pairs, 4 B per complex sample: crn_sense_run_device_sc16): half the bytes
         # per sample, converted in the kernel's first pass, outputs bit-identical to the float path on the same samples
         wire = torch.empty(n_samples * 2, dtype=torch.int16, device=dev)

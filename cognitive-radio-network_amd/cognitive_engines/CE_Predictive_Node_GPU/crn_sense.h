@@ -193,6 +193,12 @@ CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epo
  * unwindowed plans and for the Welch configuration (periodic Hann, whole frames, energy mode): CRN_ERR_ARG otherwise. */
 CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                                       int64_t epoch_stride, const crn_out *d_out, void *stream);
+/* The constant of the int16 -> float conversion that wire-format launches stand for: a sample is k / full_scale.  32768 (the
+ * default) is a power of two, applied once per epoch and exact — that is what makes the outputs bit-identical to the float path.
+ * A converter with another constant (UHD's sc16 -> fc32 scales by 1/32767) is matched by naming it here: magnitudes then carry
+ * 1/full_scale and energies its square, and the outputs equal the float path's on floats converted with that constant to within
+ * rounding (~1e-7 relative) instead of bit for bit. */
+CRN_API int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale);
 /* Complex floats -> wire format on the device (rounded to the nearest of the 65536 levels, clipped): n_samples complex samples. */
 CRN_API int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream);
 
@@ -429,7 +435,8 @@ typedef struct crn_synth_cfg {
   int32_t adc_bits;       /* 0: full fp32 samples.  2..24: every component rounded to a multiple of 2^-(adc_bits - 1) and clipped to
                            * [-1, 1): what a radio delivers — the reference's USRPs send 16-bit integers over the wire (4 bytes per
                            * complex sample: the 363-364 samples of a 1500-byte packet, src/extensible_cognitive_radio.cpp:1263-1265),
-                           * which UHD converts to the complex floats of recv(.., COMPLEX_FLOAT32, ..) (:1071-1072) */
+                           * which UHD converts to the complex floats of recv(.., COMPLEX_FLOAT32, ..) (:1071-1072) with a constant
+                           * of its own (1/32767: the values then are not on this power-of-two grid) */
 } crn_synth_cfg;
 
 /* crn_synth_fill_device with a traffic model and a signal kind.  crn_synth_fill_device(.., seed,

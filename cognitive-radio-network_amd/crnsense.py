@@ -26,7 +26,7 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
-    "crn_sense_run_device_sc16", "crn_pack_sc16_device",
+    "crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
@@ -129,6 +129,7 @@ def lib():
                                            C.POINTER(Out), C.c_void_p]
         L.crn_sense_run_device_sc16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                                 C.POINTER(Out), C.c_void_p]
+        L.crn_sense_set_wire_full_scale.argtypes = [C.c_void_p, C.c_double]
         L.crn_pack_sc16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.crn_sense_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                          C.POINTER(Out)]
@@ -271,6 +272,9 @@ class Sensor:
         fn = lib().crn_sense_run_device_sc16 if sc16 else lib().crn_sense_run_device
         check(fn(self._h, iq_ptr, n_epochs, L, epoch_stride, C.byref(o), C.c_void_p(stream or None)),
               "crn_sense_run_device_sc16" if sc16 else "crn_sense_run_device")
+
+    def set_wire_full_scale(self, full_scale):
+        check(lib().crn_sense_set_wire_full_scale(self._h, float(full_scale)), "crn_sense_set_wire_full_scale")
 
     def pack_sc16_device(self, iq_ptr, n_samples, out_ptr, stream=0):
         """complex floats -> int16 pairs on the device (n_samples complex samples)."""

@@ -48,6 +48,7 @@ struct crn_handle {
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
   double window_power = 0.0;   // sum of the squared fp32 window values (crn_monitor_rows_device)
+  double wire_full_scale = 32768.0;   // crn_sense_set_wire_full_scale
   float *d_nf_scratch = nullptr;   // crn_noise_floor_device: per-epoch medians + the result
   void *h_small = nullptr;     // pinned in-place buffer of run_host's small batches (samples | results)
   size_t h_small_bytes = 0;
@@ -469,6 +470,10 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   p.hann_sym = c.window == CRN_WINDOW_HANN;
   p.aligned_shift = d_out->spectrum == nullptr ? h->aligned_shift : 0;
   p.row_mask = h->row_mask;
+  {  // 1 / full scale for a sum of magnitudes, its square for energies (2^-15 / 2^-30 by default: exact)
+    const double u = 1.0 / h->wire_full_scale;
+    p.wire_unscale = (float)(c.mode == CRN_MODE_REF_MAG ? u : u * u);
+  }
   p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;
   p.ann_out = (c.decide == CRN_DECIDE_ANN || h->variant == 17) ? d_out->ann_out : nullptr;  // 17: trace stamps
@@ -507,6 +512,13 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
 int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                               int64_t epoch_stride, const crn_out *d_out, void *stream) {
   return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, true);
+}
+
+int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  if (!(full_scale >= 1.0 && full_scale <= 65536.0)) return crn::fail(CRN_ERR_ARG, "full_scale must be in 1..65536");
+  h->wire_full_scale = full_scale;
+  return CRN_OK;
 }
 
 int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream) {

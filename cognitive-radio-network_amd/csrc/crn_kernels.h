@@ -46,6 +46,7 @@ struct SenseParams {
   int aligned_shift;       // N = 4096 and the plan is n_bands equal contiguous bands of 2^aligned_shift bins (6..8), else 0
   int hann_sym;            // the window table is a periodic Hann: w[n + N/2] = 1 - w[n] (may be folded into pass 1)
   unsigned row_mask;       // N = 4096: bit d set when some band touches bins [256 d, 256 d + 256)
+  float wire_unscale;      // wire-format launches: 1 / full scale (2^-15 by default) for a sum of magnitudes, its square for energies
   // outputs (device, nullable)
   float *features;
   double *ann_out;

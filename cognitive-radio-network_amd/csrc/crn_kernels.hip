@@ -334,9 +334,11 @@ CRN_DEV void unpack_frame(cx (&u)[16]) {
 // The 1 / 32768 of that conversion is a power of two: it commutes with every rounding on the way (butterflies, |X|, the K-frame
 // mean), so it is applied once per epoch where the accumulated sums leave the frame loop — 2^-15 on a sum of magnitudes,
 // 2^-30 on a sum of energies — instead of twice per sample, and the results stay bit-identical to the float path's.
+// (The constant comes with the launch — crn_sense_set_wire_full_scale — because converters differ: 2^-15 keeps the bit-identity,
+// any other full scale gives the float path's results on floats converted with THAT constant to within rounding.)
 template <class C>
-CRN_DEV float sc_unscale(float x) {
-  if constexpr (C::SC16) return x * (C::MAG ? 0x1p-15f : 0x1p-30f);
+CRN_DEV float sc_unscale(float x, const SenseParams &p) {
+  if constexpr (C::SC16) return x * p.wire_unscale;
   else return x;
 }
 
@@ -1013,7 +1015,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
         }
       }
       if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
-      const float f = sc_unscale<C>(__fdiv_rn(sum, Kf));
+      const float f = sc_unscale<C>(__fdiv_rn(sum, Kf), p);
       const bool in = b < nb;
       if (p.decide == CRN_DECIDE_THRESHOLD_K) {
         const float ref = p.ref_band >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), p.ref_band)) : 1.0f;
@@ -1092,8 +1094,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     if constexpr ((C::OPT & kTrace) != 0) tr3 = __builtin_amdgcn_s_memtime();
     // the first team of the group stores and decides; lane b holds band b (n_bands <= 16)
     if (t < TEAM) {
-      const float fs1 = MAG ? sc_unscale<C>(fsum) : fsum;
-      const float f = MAG ? fs1 * fs1 : sc_unscale<C>(__fdiv_rn(fsum, Kf));  // .cpp:194-197
+      const float fs1 = MAG ? sc_unscale<C>(fsum, p) : fsum;
+      const float f = MAG ? fs1 * fs1 : sc_unscale<C>(__fdiv_rn(fsum, Kf), p);  // .cpp:194-197
       const int half = TEAM == 32 ? (tid & 32) : 0;             // two groups share a wave at T = 32
       auto from_lane = [&](int b) {
         const float lo_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), b));
@@ -1155,7 +1157,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const float x = spec[spec_phys(t + T * r)];
-        dst[t + T * r] = sc_unscale<C>(MAG ? x : __fdiv_rn(x, Kf));
+        dst[t + T * r] = sc_unscale<C>(MAG ? x : __fdiv_rn(x, Kf), p);
       }
     }
 
@@ -1219,8 +1221,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
         }
         while (k < hi) sum += spec[spec_phys(k++)];
       }
-      const float msum = MAG ? sc_unscale<C>(sum) : sum;
-      featl[b] = MAG ? msum * msum : sc_unscale<C>(__fdiv_rn(sum, Kf));  // .cpp:194-197
+      const float msum = MAG ? sc_unscale<C>(sum, p) : sum;
+      featl[b] = MAG ? msum * msum : sc_unscale<C>(__fdiv_rn(sum, Kf), p);  // .cpp:194-197
     }
     if constexpr ((C::OPT & kTrace) != 0) tr2 = __builtin_amdgcn_s_memtime();  // LDS form: this wave's band sums done
     if constexpr (G::XWAVE) __syncthreads();

@@ -128,3 +128,36 @@ def test_wire_format_ring_matches_the_float_ring(built):
         ring.close()
         sn.close()
     assert got[True] == got[False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ref512_L364", "energy4096", "welch1024"])
+def test_wire_format_with_another_converter_constant(built, mode):
+    """UHD's sc16 -> fc32 converter scales by 1/32767, not 1/32768.  crn_sense_set_wire_full_scale(32767): the wire path against the
+    float path fed k * float(1/32767) — no longer bit for bit (the float path rounds the scaled samples one by one), equal to ~1e-6."""
+    import torch
+    cfg, L = {"ref512_L364": (cs.cfg_reference(), 364), "energy4096": (cs.cfg_energy_scaled(4096, 4.0), 4096),
+              "welch1024": (cs.cfg_welch(1024, 8, 64), 1024)}[mode]
+    n = 25
+    need = cs.samples_needed(cfg, n, L)
+    rng = np.random.default_rng(5)
+    raw = rng.integers(-4000, 4000, (need, 2), dtype=np.int16)
+    host_f = (raw.astype(np.float32) * np.float32(1.0 / 32767.0)).ravel()
+    s = cs.Sensor(cfg)
+    with pytest.raises(cs.CrnError):
+        s.set_wire_full_scale(0.5)
+    s.set_wire_full_scale(32767.0)
+    feats = [torch.zeros(n, cfg.n_bands, device="cuda") for _ in range(2)]
+    spec = [torch.zeros(n, cfg.fft_len, device="cuda") for _ in range(2)]
+    dec = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    ann = [torch.zeros(n, 3, dtype=torch.float64, device="cuda") for _ in range(2)]
+    for i, (buf, sc) in enumerate(((torch.from_numpy(host_f).cuda(), False), (torch.from_numpy(raw).cuda(), True))):
+        s.run_device(buf.data_ptr(), n, L, {"features": feats[i].data_ptr(), "ann_out": ann[i].data_ptr(), "decision": dec[i].data_ptr(),
+                                            "occupancy": 0, "spectrum": spec[i].data_ptr()}, sc16=sc)
+    torch.cuda.synchronize()
+    f0, f1 = feats[0].cpu().numpy(), feats[1].cpu().numpy()
+    assert not np.array_equal(f0, f1) and np.allclose(f0, f1, rtol=2e-6, atol=0)
+    assert np.allclose(spec[0].cpu().numpy(), spec[1].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(spec[0].mean()))
+    if cfg.decide == cs.DECIDE_ANN:
+        assert torch.equal(dec[0], dec[1])
+    s.close()
