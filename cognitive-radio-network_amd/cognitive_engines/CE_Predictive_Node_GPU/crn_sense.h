@@ -199,7 +199,8 @@ CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_
  * 1/full_scale and energies its square, and the outputs equal the float path's on floats converted with that constant to within
  * rounding (~1e-7 relative) instead of bit for bit. */
 CRN_API int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale);
-/* Complex floats -> wire format on the device (rounded to the nearest of the 65536 levels, clipped): n_samples complex samples. */
+/* Complex floats -> wire format on the device: round(x * full_scale) (the handle's: 32768 unless crn_sense_set_wire_full_scale
+ * changed it), clipped to int16; n_samples complex samples. */
 CRN_API int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream);
 
 /* Host-buffer convenience used by the engine wrapper: H2D, run, D2H, synchronise. */

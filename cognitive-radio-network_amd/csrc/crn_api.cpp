@@ -525,7 +525,7 @@ int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, in
   if (!h || !d_iq || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
   if (n_samples < 0) return crn::fail(CRN_ERR_ARG, "n_samples < 0");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  HIP_TRY(crn::launch_pack_sc16(d_iq, n_samples, d_out, static_cast<hipStream_t>(stream)));
+  HIP_TRY(crn::launch_pack_sc16(d_iq, n_samples, d_out, (float)h->wire_full_scale, static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }
 

@@ -109,7 +109,7 @@ hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream);
 constexpr int kNoiseFloorMaxEpochs = 4096;
 hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
-hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, hipStream_t stream);
+hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 
 }  // namespace crn

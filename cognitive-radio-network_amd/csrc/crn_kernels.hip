@@ -2106,20 +2106,20 @@ hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream) {
 }
 
 // complex floats -> the radio's wire format (int16 pairs, full scale 32768): crn_pack_sc16_device
-__global__ __launch_bounds__(256) void pack_sc16_kernel(const float2 *iq, long long n, short2 *out) {
+__global__ __launch_bounds__(256) void pack_sc16_kernel(const float2 *iq, long long n, short2 *out, float full_scale) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float2 v = iq[i];
-    out[i] = make_short2((short)fminf(fmaxf(rintf(v.x * 32768.f), -32768.f), 32767.f), (short)fminf(fmaxf(rintf(v.y * 32768.f), -32768.f), 32767.f));
+    out[i] = make_short2((short)fminf(fmaxf(rintf(v.x * full_scale), -32768.f), 32767.f), (short)fminf(fmaxf(rintf(v.y * full_scale), -32768.f), 32767.f));
   }
 }
 
-hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, hipStream_t stream) {
+hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream) {
   if (n_samples <= 0) return hipSuccess;
   long long blocks = (n_samples + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(pack_sc16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float2 *>(iq), n_samples,
-                     reinterpret_cast<short2 *>(out));
+                     reinterpret_cast<short2 *>(out), full_scale);
   return hipGetLastError();
 }
 

@@ -142,6 +142,7 @@ def test_wire_format_with_another_converter_constant(built, mode):
     need = cs.samples_needed(cfg, n, L)
     rng = np.random.default_rng(5)
     raw = rng.integers(-4000, 4000, (need, 2), dtype=np.int16)
+    raw[:8] = [(32767, -32768), (-32768, 32767), (20000, -20000), (16384, 16383), (-16384, -16385), (1, -1), (0, 0), (30000, 29999)]
     host_f = (raw.astype(np.float32) * np.float32(1.0 / 32767.0)).ravel()
     s = cs.Sensor(cfg)
     with pytest.raises(cs.CrnError):
@@ -155,6 +156,10 @@ def test_wire_format_with_another_converter_constant(built, mode):
         s.run_device(buf.data_ptr(), n, L, {"features": feats[i].data_ptr(), "ann_out": ann[i].data_ptr(), "decision": dec[i].data_ptr(),
                                             "occupancy": 0, "spectrum": spec[i].data_ptr()}, sc16=sc)
     torch.cuda.synchronize()
+    packed = torch.zeros(need, 2, dtype=torch.int16, device="cuda")      # the packer uses the same constant: exact inverse again
+    s.pack_sc16_device(torch.from_numpy(host_f).cuda().data_ptr(), need, packed.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), raw)
     f0, f1 = feats[0].cpu().numpy(), feats[1].cpu().numpy()
     assert not np.array_equal(f0, f1) and np.allclose(f0, f1, rtol=2e-6, atol=0)
     assert np.allclose(spec[0].cpu().numpy(), spec[1].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(spec[0].mean()))
