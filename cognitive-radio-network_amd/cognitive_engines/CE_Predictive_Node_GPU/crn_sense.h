@@ -189,8 +189,8 @@ CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epo
  * instead of 8 — what the reference's USRPs put on the network (src/extensible_cognitive_radio.cpp:1263-1265: 363-364 samples per
  * 1500-byte packet) and UHD's recv converts to the complex floats of ce_usrp_rx_buffer (:1071-1072).  The kernel converts in its
  * first pass (int16 / 32768, exact in fp32), so every output is bit-identical to crn_sense_run_device on the converted floats,
- * while HBM holds and streams half the bytes.  Same arguments otherwise (strides in samples; d_iq 4-byte aligned).  Provided for
- * unwindowed plans and for the Welch configuration (periodic Hann, whole frames, energy mode): CRN_ERR_ARG otherwise. */
+ * while HBM holds and streams half the bytes.  Same arguments otherwise (strides in samples; d_iq 4-byte aligned); every configuration
+ * the float entry point takes. */
 CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                                       int64_t epoch_stride, const crn_out *d_out, void *stream);
 /* The constant of the int16 -> float conversion that wire-format launches stand for: a sample is k / full_scale.  32768 (the

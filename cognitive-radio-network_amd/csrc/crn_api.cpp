@@ -492,9 +492,6 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   const hipError_t le = crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT, h->variant,
                                           static_cast<hipStream_t>(stream), sc16);
   if (slot >= 0) (void)hipEventRecord(h->t_stop[slot], static_cast<hipStream_t>(stream));   // also after a failed launch: the slot must complete
-  if (le == hipErrorNotSupported)
-    return crn::fail(CRN_ERR_ARG, "wire-format input is provided for unwindowed plans and for the Welch configuration (periodic Hann, "
-                                  "whole frames, energy mode) only");
   if (le != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("launch_sense: ") + hipGetErrorString(le));
   // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
   const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);

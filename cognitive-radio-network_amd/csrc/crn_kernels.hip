@@ -1753,13 +1753,14 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   return hipErrorInvalidValue;
 }
 
-// Wire-format input (kSc16): the default kernels of every size and mode, the plain 4096-point kernel's three forms, and the
-// Welch configuration (periodic Hann, whole frames, energy).  Other windowed combinations are not compiled in wire format.
+// Wire-format input (kSc16): the default kernels of every size, mode and window, the plain 4096-point kernel's three forms, and the
+// Welch configuration's kernel (periodic Hann, whole frames, energy).
 template <int R3>
 static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
   if (win) {
-    if (mag || !p.hann_sym || p.L != Geo<R3>::N) return hipErrorNotSupported;
+    // everything that is not the Welch configuration's kernel: the generic windowed kernels (window table in registers)
+    if (mag || !p.hann_sym || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2>(p, mag, win, stream);
     if constexpr (R3 == 16) {
       if (p.aligned_shift != 0)
         return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);

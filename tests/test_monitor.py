@@ -65,6 +65,24 @@ def test_spectrum_monitor_tool_matches_float64(built, tmp_path, kind, fft, frame
     assert "peak bin of last averaged row" in r.stdout
 
 
+def test_spectrum_monitor_tool_on_a_wire_format_capture(built, tmp_path):
+    """--sc16: a capture of int16 pairs (what `uhd_rx_cfile --type short` writes) goes to the GPU as it is; the rows are the ones the
+    float capture of the same samples gives, bit for bit."""
+    fft, frames, n_rows = 1024, 2, 11
+    x = _capture(n_rows, fft, frames, seed=9)
+    raw = np.round(np.stack([x.real, x.imag], axis=1) * 32768.0 * 8).astype(np.int16)        # x 8: use a few more of the 16 bits
+    (tmp_path / "cap.sc16").write_bytes(raw.tobytes())
+    (raw.astype(np.float32) / np.float32(32768.0)).tofile(tmp_path / "cap.c64")
+    outs = []
+    for name, extra in (("cap.c64", []), ("cap.sc16", ["--sc16"])):
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spectrum_monitor.py"), str(tmp_path / name), "--fft", str(fft),
+                            "--frames", str(frames), "--out", str(out)] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["waterfall_db"], outs[1]["waterfall_db"]) and np.array_equal(outs[0]["average_db"], outs[1]["average_db"])
+
+
 def test_monitor_and_reserve_argument_errors(built):
     import ctypes as C
     import torch

@@ -35,6 +35,16 @@ def _cfgs():
         yield f"welch{n}", cs.cfg_welch(n, 8, 64), n
     c = cs.cfg_welch(4096, 5, 16)               # 256-bin aligned bands
     yield "welch4096_16bands", c, 4096
+    for n in (512, 1024, 2048, 4096):           # the generic windowed kernels: Blackman-Harris (the monitor's window), magnitudes, short frames
+        c = cs.cfg_energy_scaled(n, 4.0)
+        c.window = cs.WINDOW_BLACKMAN_HARRIS
+        yield f"bh{n}", c, n
+    c = cs.cfg_welch(1024, 8, 64)
+    c.mode = cs.MODE_REF_MAG
+    yield "welch1024_mag", c, 1024
+    c = cs.cfg_energy_scaled(2048, 4.0)
+    c.window = cs.WINDOW_HANN
+    yield "hann2048_L1500", c, 1500
 
 
 @pytest.mark.gpu
@@ -84,18 +94,15 @@ def test_wire_format_is_bit_identical_to_the_float_path(built, name, cfg, L, wan
 
 
 @pytest.mark.gpu
-def test_wire_format_refuses_what_is_not_compiled(built):
+def test_wire_format_argument_checks(built):
     import torch
     cfg = cs.cfg_welch(1024, 8, 64)
-    cfg.window = cs.WINDOW_BLACKMAN_HARRIS
     s = cs.Sensor(cfg)
     x = torch.zeros(cs.samples_needed(cfg, 4), 2, dtype=torch.int16, device="cuda")
     f = torch.zeros(4, 64, device="cuda")
-    with pytest.raises(cs.CrnError) as ei:
-        s.run_device(x.data_ptr(), 4, 1024, {"features": f.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0}, sc16=True)
-    assert "wire-format" in str(ei.value)
-    with pytest.raises(cs.CrnError):
+    with pytest.raises(cs.CrnError) as ei:   # int16 pairs are 4-byte units
         s.run_device(x.data_ptr() + 2, 4, 1024, {"features": f.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0}, sc16=True)
+    assert "4-byte aligned" in str(ei.value)
     s.close()
 
 

@@ -23,11 +23,12 @@ sys.path.insert(0, os.path.join(ROOT, "cognitive-radio-network_amd"))
 import crnsense as cs  # noqa: E402
 
 
-def run(iq_file, fft=1024, frames=1, alpha=0.1, kind="gnuradio", device=0, chunk_rows=4096):
+def run(iq_file, fft=1024, frames=1, alpha=0.1, kind="gnuradio", device=0, chunk_rows=4096, sc16=False):
     import torch
     cfg = cs.cfg_energy_scaled(fft, 4.0)
     cfg.window, cfg.decide, cfg.frames_per_epoch, cfg.device = cs.WINDOW_BLACKMAN_HARRIS, cs.DECIDE_NONE, frames, device
-    iq = np.fromfile(iq_file, dtype=np.float32)
+    # sc16: a capture in the radio's wire format (int16 pairs, e.g. `uhd_rx_cfile --type short`): it stays int16 in HBM
+    iq = np.fromfile(iq_file, dtype=np.int16 if sc16 else np.float32)
     spe = cs.samples_per_epoch(cfg)
     n_rows = iq.size // (2 * spe)
     if n_rows < 1:
@@ -44,8 +45,8 @@ def run(iq_file, fft=1024, frames=1, alpha=0.1, kind="gnuradio", device=0, chunk
     k = cs.MONITOR_GNURADIO if kind == "gnuradio" else cs.MONITOR_PSD
     for r0 in range(0, n_rows, chunk_rows):
         n = min(chunk_rows, n_rows - r0)
-        s.run_device(d_iq.data_ptr() + r0 * spe * 8, n, fft, {"features": 0, "ann_out": 0, "decision": 0, "occupancy": 0,
-                                                              "spectrum": spec.data_ptr()}, stream=stream)
+        s.run_device(d_iq.data_ptr() + r0 * spe * (4 if sc16 else 8), n, fft, {"features": 0, "ann_out": 0, "decision": 0, "occupancy": 0,
+                                                                             "spectrum": spec.data_ptr()}, stream=stream, sc16=sc16)
         s.monitor_rows_device(spec.data_ptr(), n, k, alpha, r0 == 0, state.data_ptr(),
                               water.data_ptr() + r0 * fft * 4, avg.data_ptr() + r0 * fft * 4, stream=stream)
     torch.cuda.synchronize()
@@ -63,8 +64,9 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=4096)
     ap.add_argument("--out", default="psd.npz")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--sc16", action="store_true", help="the capture holds int16 pairs (the radio's wire format) instead of complex64")
     a = ap.parse_args()
-    water, avg = run(a.iq_file, a.fft, a.frames, a.alpha, a.kind, a.device, a.chunk_rows)
+    water, avg = run(a.iq_file, a.fft, a.frames, a.alpha, a.kind, a.device, a.chunk_rows, a.sc16)
     np.savez(a.out, waterfall_db=water, average_db=avg)
     print(f"{water.shape[0]} rows x {a.fft} bins -> {a.out}; peak bin of last averaged row: {int(avg[-1].argmax()) - a.fft // 2:+d}")
 
