@@ -111,3 +111,26 @@ def test_bench_wire_format_mode(built):
     assert "NOT THE HEADLINE CONFIGURATION" in d["config"]["workload"] and d["roofline"]["traffic"] is None
     d = _run("--cpu-epochs", "0", "--wire-format", "--mode", "welch")
     assert "wire format" in d["config"]["workload"]
+
+
+def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
+    """bench.py's whole N > 1 flow on hardware, the way the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 ..
+    bench.py --gpus 2`): gloo control plane, unique id made by rank 0 through the C ABI and broadcast, streams sharded over the
+    ranks, crn_comm_* slots, barriers, max-over-ranks timing, every rank finding its block at its place in the gathered vector, one
+    JSON line from rank 0.  Real RCCL refuses two ranks on one device and the pool hands out one GPU: the wire is
+    tests/harness/libfake_rccl_mp.so (shared memory between the two processes), everything above it is the product."""
+    fake = os.path.join(ROOT, "tests", "harness", "libfake_rccl_mp.so")
+    assert os.path.exists(fake)
+    env = dict(os.environ, CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
+    for extra in ([], ["--mode", "scan"]):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                              "--epochs", "2048", "--cpu-epochs", "0", *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["epochs_per_gpu"] == 2048
+        assert d["config"]["parallelism"].startswith("stream-sharded x2") and "crn_comm_" in d["config"]["parallelism"]
+        assert "FALLBACK" not in d["config"]["parallelism"] and d["cpu_baseline"] is None
+        assert d["value"] > 0 and d["ms_per_step"] > 0
