@@ -4,6 +4,7 @@ slot reuse, ordering against the launch stream) and the sensing kernel writing s
 GPU: the entry points fail cleanly.  The two-rank layout (rank order, slot reuse) is covered on CPU by
 tests/test_sharding_gloo.py with the gloo twin of the same slot logic."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -73,10 +74,25 @@ def test_scan_node_cpp_program_over_the_c_abi(built, tmp_path):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", "scan_node")
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    out = subprocess.run([exe, "4", "256", "10", str(tmp_path / "rccl_id")], capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run([exe, "4", "256", "10", str(tmp_path / "rccl_id")], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank 0/1")][0]
     assert "own block in place: yes" in line and "driven channel flagged in 1024 of 1024 epochs" in line
     occupied = float(line.split(" epochs, ")[-1].split()[0])
     assert 1.0 <= occupied < 8.0       # the driven channel, plus splatter where the traffic changes inside a frame
     print(line)
+
+
+@pytest.mark.gpu
+def test_scan_node_two_processes_on_one_gpu(built):
+    """cfg4 without Python as TWO processes (tools/run_scan_node.sh 2, both on the box's one GPU) over the shared-memory stand-in for
+    RCCL: unique id through a file, streams split between the ranks, thresholds calibrated per rank, every rank's block found at its
+    place in the gathered vector (the program checks that itself and exits non-zero otherwise)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ONE_GPU="1", CRN_RCCL_LIB=os.path.join(root, "tests", "harness", "libfake_rccl_mp.so"))
+    out = subprocess.run(["bash", os.path.join(root, "tools", "run_scan_node.sh"), "2", "8", "64", "5"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank")]
+    assert len(lines) == 2 and any("rank 0/2" in ln for ln in lines) and any("rank 1/2" in ln for ln in lines), out.stdout
