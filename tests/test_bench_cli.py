@@ -123,9 +123,10 @@ def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
     assert os.path.exists(fake)
     env = dict(os.environ, CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
     for extra in ([], ["--mode", "scan"]):
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                              "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                              "--epochs", "2048", "--cpu-epochs", "0", *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        from test_comm import _run_group   # own process group: a timeout must not leave the two ranks behind
+        out = _run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--epochs", "2048", "--cpu-epochs", "0", *extra], 300, env, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
         assert len(lines) == 1, out.stdout[-2000:]
