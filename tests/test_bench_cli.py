@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 
 def _run(*extra, epochs=("--epochs", "512")):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                          *epochs, *(() if "--live" in extra else ("--no-live-traffic",)),
-                          *[e for e in extra if e != "--live"]], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    from test_comm import _run_group   # own process group, one retry after a timeout (a communicator bring-up hung once on one box)
+    out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
+                      *epochs, *(() if "--live" in extra else ("--no-live-traffic",)),
+                      *[e for e in extra if e != "--live"]], 300, env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout            # exactly one line, whatever the libraries print
