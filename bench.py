@@ -88,6 +88,10 @@ def live_counters(args, epochs, passes):
              "--epochs", str(epochs)]
     if args.frames > 0:
         child += ["--frames", str(args.frames)]
+    if getattr(args, "wire_format", False):
+        child += ["--wire-format"]
+    elif getattr(args, "adc_bits", 0):
+        child += ["--adc-bits", str(args.adc_bits)] + (["--uhd-scale"] if getattr(args, "uhd_scale", False) else [])
     got = {}
     try:
         for i, group in enumerate(passes):
@@ -249,7 +253,7 @@ def main():
         workload += " [DIAGNOSTIC: all-zero input]"
     else:
         if args.wire_format:
-            args.adc_bits, args.no_alt, args.no_live_traffic = 16, True, True
+            args.adc_bits, args.no_alt = 16, True
         sc0 = cs.SynthCfg()
         sc0.seed, sc0.noise_power, sc0.signal_rms, sc0.tones_per_band = 0xC0FFEE + 1000 * rank, 1e-6, 0.02, 8
         sc0.pu_model, sc0.signal_kind, sc0.n_streams, sc0.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, args.adc_bits

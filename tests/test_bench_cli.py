@@ -109,7 +109,10 @@ def test_bench_wire_format_mode(built):
     wire buffer was packed from), bytes per step are 4 per sample, and the workload says it is not the headline configuration."""
     d = _run("--cpu-epochs", "0", "--wire-format")
     assert d["config"]["bytes_per_gpu_per_step"] == 512 * 40960 * 4
-    assert "NOT THE HEADLINE CONFIGURATION" in d["config"]["workload"] and d["roofline"]["traffic"] is None
+    assert "NOT THE HEADLINE CONFIGURATION" in d["config"]["workload"] and d["roofline"]["traffic"] is None   # (--no-live-traffic here)
+    d = _run("--cpu-epochs", "0", "--wire-format", "--live")                  # measured in the run: 4 B per sample, read once
+    assert d["roofline"]["traffic_source"].startswith("measured in this run")
+    assert 1.0 <= d["roofline"]["traffic"] / d["config"]["bytes_per_gpu_per_step"] < 1.02
     d = _run("--cpu-epochs", "0", "--wire-format", "--mode", "welch")
     assert "wire format" in d["config"]["workload"]
 
