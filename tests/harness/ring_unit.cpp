@@ -264,6 +264,43 @@ int main() {
     REQUIRE(crn_ingest_push_sc16(g, 0, ipk.data()) == CRN_ERR_STATE);
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
+  // 8. random schedules (seeded): any number of streams and epochs per batch, streams picked at random (so their epochs
+  // interleave arbitrarily), flushes at random moments, a "GPU" of random latency, callers that wait or retry on BUSY — every
+  // complete epoch exactly once, in order per stream, with exactly its own packets; epochs still open at the end never appear
+  for (unsigned seed = 1; seed <= 12; seed++) {
+    srand(seed);
+    const int S = 1 + rand() % 6, B = 1 + rand() % 5, L = 8 + rand() % 57;
+    g_fake_gpu_latency_ns = (rand() % 3 == 0) ? 0 : 20000 + rand() % 300000;
+    Feeder f{L};
+    REQUIRE(crn_ingest_create(&h, S, L, B, &g) == CRN_OK);
+    std::vector<long> done(S, 0);
+    std::vector<int> pkt(S, 0);
+    std::vector<crn_epoch_result> all;
+    const int steps = 400 + rand() % 1200;
+    for (int it = 0; it < steps; it++) {
+      const int st = rand() % S;
+      std::vector<float> pk = f.packet(st, done[st], pkt[st]);
+      int rc;
+      while ((rc = crn_ingest_push(g, st, pk.data())) == CRN_ERR_BUSY) {
+        if (rand() % 2) REQUIRE(crn_ingest_wait(g) == CRN_OK);
+        collect(g, &all);
+      }
+      REQUIRE(rc == CRN_OK);
+      if (++pkt[st] == 10) { pkt[st] = 0; done[st]++; }
+      if (rand() % 50 == 0) REQUIRE(crn_ingest_flush(g) == CRN_OK);
+      if (rand() % 7 == 0) collect(g, &all);
+    }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    verify(all, f, S, done);
+    crn_ingest_stats st;
+    REQUIRE(crn_ingest_get_stats(g, &st) == CRN_OK);
+    long total = 0;
+    for (int i = 0; i < S; i++) total += done[i];
+    REQUIRE(st.packets == steps && st.epochs_ready == total && st.epochs_polled == total && st.batches_failed == 0);
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  }
+  g_fake_gpu_latency_ns = 0;
   printf("ring_unit: ok\n");
   return 0;
 }
