@@ -1,6 +1,6 @@
 // comm_unit.cpp — TEST INFRASTRUCTURE.  The occupancy exchange (csrc/crn_comm.cpp) as a world of TWO ranks without a GPU:
 // two threads, each with its own communicator, the HIP calls replaced by host stand-ins defined here (link-time: libamdhip64 is
-// not linked) and RCCL by tests/harness/libfake_rccl.so ($CRN_RCCL_LIB).  Checks what the unattended 8-GPU run relies on:
+// not linked) and RCCL by tests/harness/libfake_rccl.so ($CRN_RCCL_LIB); worlds of 1, 2, 3, 5 and 8 ranks x 1, 2, 3 slots.  Checks what the unattended 8-GPU run relies on:
 // every rank receives [rank 0 block][rank 1 block], slot i % depth, slots reused after `depth` steps, sizes and offsets right.
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -43,15 +43,17 @@ static int g_failures = 0;
     }                                                                                      \
   } while (0)
 
-static void rank_main(int rank, int world, const uint8_t *id, int64_t bytes) {
+static void rank_main(int rank, int world, const uint8_t *id, int64_t bytes, int depth) {
   crn_comm *c = NULL;
-  REQUIRE(crn_comm_create(0, rank, world, id, bytes, 2, &c) == CRN_OK);
-  uint8_t *slot_ptr[2] = {NULL, NULL};
-  for (int64_t step = 0; step < 5; step++) {
+  REQUIRE(crn_comm_create(0, rank, world, id, bytes, depth, &c) == CRN_OK);
+  uint8_t *slot_ptr[16] = {NULL};
+  for (int64_t step = 0; step < 3 * depth + 2; step++) {
     uint8_t *local = NULL;
     REQUIRE(crn_comm_local(c, step, NULL, &local) == CRN_OK);
-    if (step < 2) slot_ptr[step] = local;
-    REQUIRE(local == slot_ptr[step % 2]);                                 // two slots, alternating, reused
+    if (step < depth) slot_ptr[step] = local;
+    REQUIRE(local == slot_ptr[step % depth]);                             // `depth` slots, taken in turn, reused
+    for (int64_t other = 0; other < step && other < depth; other++)
+      if (other != step % depth) REQUIRE(slot_ptr[other] != local);       // and distinct
     for (int64_t i = 0; i < bytes; i++) local[i] = (uint8_t)(100 * rank + 10 * step + (i & 7));
     REQUIRE(crn_comm_allgather(c, step, NULL) == CRN_OK);
     REQUIRE(crn_comm_finish(c, NULL) == CRN_OK);
@@ -78,13 +80,15 @@ int main(int argc, char **argv) {
   }
   crn_comm *bad = NULL;
   if (crn_comm_create(0, 2, 2, id, 64, 2, &bad) != CRN_ERR_ARG || crn_comm_create(0, 0, 2, id, 0, 2, &bad) != CRN_ERR_ARG) return 1;
-  for (int world = 1; world <= 2; world++) {
-    uint8_t gid[CRN_COMM_ID_BYTES];
-    if (crn_comm_unique_id(gid) != CRN_OK) return 1;
-    std::vector<std::thread> th;
-    for (int r = 0; r < world; r++) th.emplace_back(rank_main, r, world, gid, (int64_t)(4 * 64));   // 4 epochs x 64 channels
-    for (std::thread &t : th) t.join();
-  }
+  const int worlds[] = {1, 2, 3, 5, 8}, depths[] = {1, 2, 3};
+  for (int world : worlds)
+    for (int depth : depths) {
+      uint8_t gid[CRN_COMM_ID_BYTES];
+      if (crn_comm_unique_id(gid) != CRN_OK) return 1;
+      std::vector<std::thread> th;
+      for (int r = 0; r < world; r++) th.emplace_back(rank_main, r, world, gid, (int64_t)(4 * 64 + 3 * depth), depth);   // ~4 epochs x 64 channels
+      for (std::thread &t : th) t.join();
+    }
   if (g_failures) return 1;
   printf("comm_unit: ok\n");
   return 0;

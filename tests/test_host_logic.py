@@ -36,7 +36,7 @@ def test_engine_control_flow_under_thread_sanitizer(built):
 
 
 def test_occupancy_exchange_as_a_world_of_two_ranks(built):
-    """tests/harness/comm_unit.cpp: csrc/crn_comm.cpp with world = 2 — two threads, one communicator each, host stand-ins for the HIP
+    """tests/harness/comm_unit.cpp: csrc/crn_comm.cpp with world = 1, 2, 3, 5 and 8 (x 1, 2, 3 slots) — one thread and one communicator per rank, host stand-ins for the HIP
     calls and tests/harness/libfake_rccl.so (really places rank r's block at offset r * count) behind $CRN_RCCL_LIB: every rank
     receives [rank 0 block][rank 1 block], slots alternate and are reused, argument errors are refused.  The hardware run at N > 1
     is the driver's; this is the same code path with everything but the wire."""
