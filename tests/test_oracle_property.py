@@ -3,7 +3,8 @@ band table (several runs per band, overlapping bands, a band that wraps around D
 Blackman-Harris window, Welch hop or disjoint frames, short packets, K from 1 to 12, absolute or reference-band thresholds.
 Features to 1e-5 (the parity bar), occupancy exactly wherever float64 leaves a margin.  No GPU."""
 import numpy as np
-from hypothesis import given, settings, strategies as st
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
 
 import crnsense as cs
 import oracle_py as orc
@@ -34,9 +35,7 @@ def plans(draw):
     return n, k, mode, win, hop, L, runs, ref_band, thr, seed
 
 
-@settings(max_examples=200, deadline=None)
-@given(plans())
-def test_oracle_matches_float64_on_random_plans(built, p):
+def _build(p):
     n, k, mode, win, hop, L, runs, ref_band, thr, seed = p
     plan = ref_f64.Plan(n=n, k=k, hop=0 if hop == n else hop, mode=mode, window=win, runs=runs, decide="threshold", thresh=tuple(thr),
                         ref_band=ref_band)
@@ -61,8 +60,10 @@ def test_oracle_matches_float64_on_random_plans(built, p):
     # error scales with the frame's total power, so a bin 60 dB under a carrier has no meaningful relative error)
     iq[0::2] += (2e-3 * np.cos(2 * np.pi * tone * t / n)).astype(np.float32)
     iq[1::2] += (2e-3 * np.sin(2 * np.pi * tone * t / n)).astype(np.float32)
-    got = orc.run(cfg, iq, n_epochs, L=L, want_spectrum=True)
-    want = ref_f64.run(plan, iq, n_epochs, L=L)
+    return cfg, plan, iq, n_epochs, L, runs, ref_band, thr, k
+
+
+def _check(got, want, runs, ref_band, thr, k):
     scale = np.maximum(np.abs(want["features"]), 1e-30)
     empty = np.array([sum(hi - lo for lo, hi in runs[b]) == 0 for b in range(len(runs))])
     assert (np.abs(got["features"] - want["features"]) / scale)[:, ~empty].max(initial=0.0) < 1e-5
@@ -76,3 +77,22 @@ def test_oracle_matches_float64_on_random_plans(built, p):
     with np.errstate(invalid="ignore", divide="ignore"):
         safe = np.isinf(lim) | (np.abs(want["features"] / lim - 1.0) > 1e-4)
     assert np.array_equal(got["occupancy"][safe], want["occupancy"][safe])
+
+
+@settings(max_examples=200, deadline=None)
+@given(plans())
+def test_oracle_matches_float64_on_random_plans(built, p):
+    cfg, plan, iq, n_epochs, L, runs, ref_band, thr, k = _build(p)
+    _check(orc.run(cfg, iq, n_epochs, L=L, want_spectrum=True), ref_f64.run(plan, iq, n_epochs, L=L), runs, ref_band, thr, k)
+
+
+@pytest.mark.gpu
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(plans())
+def test_gpu_matches_float64_on_random_plans(built, p):
+    """The HIP path through the C ABI against the same independent float64 restatement, same random plans, same bars."""
+    cfg, plan, iq, n_epochs, L, runs, ref_band, thr, k = _build(p)
+    s = cs.Sensor(cfg)
+    got = s.run_host(iq, n_epochs, L=L, want_spectrum=True)
+    s.close()
+    _check(got, ref_f64.run(plan, iq, n_epochs, L=L), runs, ref_band, thr, k)
