@@ -96,3 +96,54 @@ def test_gpu_matches_float64_on_random_plans(built, p):
     got = s.run_host(iq, n_epochs, L=L, want_spectrum=True)
     s.close()
     _check(got, ref_f64.run(plan, iq, n_epochs, L=L), runs, ref_band, thr, k)
+
+
+# ---- reference mode (|X| mean, square of sum, 4-5-3 network, cascade) on random traffic ------------------------------------------
+
+@st.composite
+def ref_traffic(draw):
+    L = draw(st.sampled_from([512, 364, 363]))
+    n_epochs = draw(st.integers(1, 6))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    # per epoch and channel: a carrier amplitude from "absent" to "strong" (the network's whole operating range)
+    amps = [[draw(st.sampled_from([0.0, 0.0, 1e-3, 3e-3, 1e-2, 3e-2])) for _ in range(3)] for _ in range(n_epochs)]
+    return L, n_epochs, seed, amps
+
+
+def _ref_case(t):
+    L, n_epochs, seed, amps = t
+    rng = np.random.default_rng(seed)
+    x = (rng.normal(0, 7.07e-4, (n_epochs, 10, L)) + 1j * rng.normal(0, 7.07e-4, (n_epochs, 10, L))).astype(np.complex64)
+    centres = (4, 70, 205)                                              # inside CH1 / CH2 / CH3 (REF_RUNS_512)
+    n = np.arange(L)
+    for e in range(n_epochs):
+        for c in range(3):
+            ph = rng.uniform(0, 2 * np.pi)
+            x[e] += (amps[e][c] * np.exp(1j * (2 * np.pi * centres[c] * n / 512 + ph))).astype(np.complex64)
+    iq = np.ascontiguousarray(x).view(np.float32).ravel()
+    return iq, n_epochs, L
+
+
+def _check_ref(got, want):
+    assert (np.abs(got["features"] - want["features"]) / np.abs(want["features"])).max() < 1e-5
+    assert np.abs(got["ann_out"] - want["ann_out"]).max() < 1e-4        # fp32 features through a steep network
+    sure = want["margin"] > 1e-3
+    assert np.array_equal(got["decision"][sure], want["decision"][sure])
+
+
+@settings(max_examples=150, deadline=None)
+@given(ref_traffic())
+def test_oracle_reference_mode_on_random_traffic(built, t):
+    iq, n_epochs, L = _ref_case(t)
+    _check_ref(orc.run(cs.cfg_reference(), iq, n_epochs, L=L), ref_f64.run(ref_f64.plan_reference(), iq, n_epochs, L=L))
+
+
+@pytest.mark.gpu
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(ref_traffic())
+def test_gpu_reference_mode_on_random_traffic(built, t):
+    iq, n_epochs, L = _ref_case(t)
+    s = cs.Sensor(cs.cfg_reference())
+    got = s.run_host(iq, n_epochs, L=L)
+    s.close()
+    _check_ref(got, ref_f64.run(ref_f64.plan_reference(), iq, n_epochs, L=L))
