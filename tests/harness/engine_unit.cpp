@@ -124,6 +124,7 @@ int main() {
     feed_epoch(ecr, e, small, 3);
     REQUIRE(e->features[0] == 10.0f * 100 * (3.0f + 0.25f));
     e->release();
+    delete e;   // (the ECR never deletes its engine; here the destructor path — release() again — runs under the sanitizers)
   }
   // ---- a slow "GPU": packets are refused while both buffers are busy; execute() never waits -------------------------------
   {
@@ -150,6 +151,7 @@ int main() {
     REQUIRE(worst_ns < 2000000);          // and no call sat out a 3 ms batch
     REQUIRE(e->epochs_closed >= 5);
     e->release();
+    delete e;   // (the ECR never deletes its engine; here the destructor path — release() again — runs under the sanitizers)
     g_fake_gpu_latency_ns = 0;
   }
   // ---- the wall-clock gate (default arguments): sensing is re-armed no sooner than every 100 ms (.cpp:127-141, .hpp:30) -----------
@@ -176,6 +178,7 @@ int main() {
       if (ecr.calls[i].name == "set_ce_sensing" && ecr.calls[i].arg == 1.0) REQUIRE(i > 0 && ecr.calls[i - 1].name == "stop_tx");
     REQUIRE(count(ecr, "set_ce_sensing", 0.0) == 3);
     e->release();
+    delete e;   // (the ECR never deletes its engine; here the destructor path — release() again — runs under the sanitizers)
   }
   printf("engine_unit: ok\n");
   return 0;

@@ -35,6 +35,18 @@ def test_engine_control_flow_under_thread_sanitizer(built):
     _run_unit("engine_unit", 2)
 
 
+def test_ring_and_engine_under_address_and_ub_sanitizers(built):
+    """The same two programs built with -fsanitize=address,undefined (they cannot share a build with ThreadSanitizer): the pinned
+    buffers' slot arithmetic, the carry-over copies of open epochs, the byte-sized layout of the wire-format ring."""
+    for name in ("ring_unit_asan", "engine_unit_asan"):
+        exe = os.path.join(HARNESS, name)
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", HARNESS, exe])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        assert "ok" in out.stdout and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[:3000]
+
+
 def test_occupancy_exchange_as_a_world_of_two_ranks(built):
     """tests/harness/comm_unit.cpp: csrc/crn_comm.cpp with world = 1, 2, 3, 5 and 8 (x 1, 2, 3 slots) — one thread and one communicator per rank, host stand-ins for the HIP
     calls and tests/harness/libfake_rccl.so (really places rank r's block at offset r * count) behind $CRN_RCCL_LIB: every rank
