@@ -17,6 +17,9 @@
 #include "CE_Predictive_Node_GPU.hpp"
 #include "fake_sense.h"
 
+// the engines are deleted through their own (most derived) type below; the base class has a non-virtual destructor, like the reference's
+#pragma GCC diagnostic ignored "-Wdelete-non-virtual-dtor"
+
 
 CognitiveEngine::CognitiveEngine() : ECR(NULL) {}
 CognitiveEngine::~CognitiveEngine() {}
