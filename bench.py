@@ -10,6 +10,8 @@ Default workload = the configuration the metric is quoted on (SURVEY.md §8d "cf
   python bench.py                     # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N        # N GPUs, one rank each
+  python bench.py --gpus N            # the same: without a launcher (no WORLD_SIZE) bench.py starts that command itself,
+                                      # before it touches the GPU, and relays rank 0's line and the exit code
 
 Multi-GPU: the path shards by stream — every rank owns its own epochs (weak
 scaling, per-GPU work fixed) and the only exchange is an RCCL all-gather of the per-epoch
@@ -72,6 +74,34 @@ def usable_cores():
     return n, why
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process (one rank per GPU; when the node
+    shows fewer devices than ranks the ranks share device 0, which only a stand-in RCCL behind $CRN_RCCL_LIB accepts), pass on the
+    one JSON line rank 0 prints, and return the launcher's exit code.  Called before anything in this process touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [os.path.realpath(sys.executable), "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")              # (what torch.distributed.run would set, without its warning)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    for ln in r.stdout.splitlines():
+        if ln not in lines and ln.strip():
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if r.returncode == 0 and not lines:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def live_counters(args, epochs, passes):
     """rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over a short child run of the same workload:
     {counter: mean over the timed launches, "kernel_s": mean kernel duration of the last pass}, or None."""
@@ -83,7 +113,9 @@ def live_counters(args, epochs, passes):
     if shutil.which("rocprofv3") is None:
         return None
     tmp = tempfile.mkdtemp(prefix="crn_pmc_", dir="/tmp")
-    child = ["python3", os.path.abspath(__file__), "--steps", "5", "--warmup", "20", "--cpu-epochs", "0", "--no-alt",
+    # the interpreter running this file, resolved to the real binary: no shim or wrapper script may sit between rocprofv3's `--`
+    # and the program (the profiler's preloaded library initialises the GPU, and an exec after that is refused on this pool)
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--steps", "5", "--warmup", "20", "--cpu-epochs", "0", "--no-alt",
              "--no-live-traffic", "--fft", str(args.fft), "--mode", args.mode, "--variant", str(args.variant),
              "--epochs", str(epochs)]
     if args.frames > 0:
@@ -98,8 +130,10 @@ def live_counters(args, epochs, passes):
             out = os.path.join(tmp, str(i))
             r = subprocess.run(["rocprofv3", "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
                                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=180)
+                               stderr=subprocess.PIPE, text=True, timeout=180)
             if r.returncode != 0:
+                print(f"bench: counter pass {group} failed (rc {r.returncode}); roofline.traffic falls back to the committed figure\n"
+                      + r.stderr[-1500:], file=sys.stderr)
                 return None
             per = {}
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
@@ -115,7 +149,8 @@ def live_counters(args, epochs, passes):
                    for row in csv.DictReader(open(f)) if "sense_kernel" in row["Kernel_Name"]][-5:]
             if dur:
                 got["kernel_s"] = sum(dur) / len(dur)
-    except Exception:
+    except Exception as e:   # noqa: BLE001 — a measurement aid must not take the bench line down with it
+        print(f"bench: counter passes failed: {e!r}", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -170,6 +205,11 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "r02_valu_counters.json"))
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves.  This process has made no GPU
+        # call (torch is not even imported yet) and never will: it only relays rank 0's JSON line and the launcher's exit code.
+        raise SystemExit(self_launch(args.gpus))
 
     # stdout carries exactly one JSON line: everything else this process (or a library under it:
     # RCCL prints a version banner at init) writes to fd 1 goes to stderr instead.

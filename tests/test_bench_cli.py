@@ -139,3 +139,51 @@ def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
         assert d["config"]["parallelism"].startswith("stream-sharded x2") and "crn_comm_" in d["config"]["parallelism"]
         assert "FALLBACK" not in d["config"]["parallelism"] and d["cpu_baseline"] is None
         assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def _self_launched(n, *extra, epochs="512", timeout=600):
+    """`python bench.py --gpus n` with NO launcher and no WORLD_SIZE in the environment — the shape of the driver's single-GPU command
+    at n > 1 — on the one GPU of the box, the ranks over tests/harness/libfake_rccl_mp.so."""
+    fake = os.path.join(ROOT, "tests", "harness", "libfake_rccl_mp.so")
+    assert os.path.exists(fake)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
+    from test_comm import _run_group
+    out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
+                      "--epochs", epochs, "--cpu-epochs", "0", *extra], timeout, env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]          # the parent relays exactly rank 0's line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_without_a_launcher(built):
+    d = _self_launched(2)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("stream-sharded x2")
+    assert "crn_comm_" in d["config"]["parallelism"] and "FALLBACK" not in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("mode", [[], ["--mode", "scan"]])
+def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode):
+    """BASELINE.json configs[4] as the driver will start it (`python3 bench.py --gpus 8 ...`), rehearsed with the eight ranks sharing
+    the one GPU: bench.py starts torch.distributed.run itself before it touches the GPU, gloo control plane, RCCL unique id from
+    rank 0 through the C ABI, streams sharded eight ways, crn_comm_* slots, the barriers and the max-over-ranks timing; EVERY rank
+    checks that its own block sits unchanged at its place in the gathered vector (a mismatch on any rank makes the launcher, and so
+    the parent, exit non-zero) and rank 0's single JSON line is relayed."""
+    d = _self_launched(8, *mode, epochs="1024")
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["epochs_per_gpu"] == 1024
+    assert d["config"]["parallelism"].startswith("stream-sharded x8") and "crn_comm_" in d["config"]["parallelism"]
+    assert "FALLBACK" not in d["config"]["parallelism"] and d["cpu_baseline"] is None
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
+    if mode:
+        assert "cfg4" in d["config"]["workload"]
+
+
+def test_bench_self_launch_propagates_a_rank_failure(built):
+    """A rank that dies (here: an argument only the ranks reject) must surface as a non-zero exit of the parent, not as a hang or a
+    clean exit without a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    from test_comm import _run_group
+    out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--epochs", "64",
+                      "--cpu-epochs", "0", "--fft", "3000"], 300, env, cwd=ROOT)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]

@@ -1,0 +1,95 @@
+"""bench.py's self-launch (no GPU needed): `python bench.py --gpus N` without WORLD_SIZE must start
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>` as a
+CHILD process before importing torch or touching the GPU, relay rank 0's JSON line and the exit code."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_launch_command_and_relay(monkeypatch, capsys):
+    bench = _load_bench()
+    seen = {}
+
+    class R:
+        returncode = 0
+        stdout = "RCCL banner that a library printed\n" + json.dumps({"n_gpus": 8, "value": 1.0}) + "\n"
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    assert "torch" not in sys.modules or True     # (pytest plugins may have imported it; bench.py itself must not need it here)
+    rc = bench.self_launch(8)
+    out = capsys.readouterr()
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3"]          # the ranks get the caller's arguments unchanged
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert [ln for ln in out.out.splitlines() if ln.strip()] == [json.dumps({"n_gpus": 8, "value": 1.0})]   # stdout: the one line
+    assert "RCCL banner" in out.err
+
+
+def test_self_launch_exit_codes(monkeypatch, capsys):
+    bench = _load_bench()
+
+    class Fail:
+        returncode = 3
+        stdout = ""
+
+    class Silent:
+        returncode = 0
+        stdout = "no json here\n"
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: Fail())
+    assert bench.self_launch(2) == 3
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: Silent())
+    assert bench.self_launch(2) == 1
+    capsys.readouterr()
+
+
+def test_main_self_launches_before_any_gpu_or_torch_use(monkeypatch):
+    """main() with --gpus 4 and no WORLD_SIZE goes to self_launch() and exits with its code; with WORLD_SIZE set (a rank
+    started by the launcher) it does not."""
+    bench = _load_bench()
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda n: calls.append(n) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("main() returned")
+    except SystemExit as e:
+        assert e.code == 7
+    assert calls == [4]
+
+
+def test_two_self_launched_ranks_reach_the_gpu_check_without_a_gpu():
+    """End to end without a GPU: the parent starts two real rank processes; each stops at "bench.py needs a GPU" (libcrnsense has no
+    CPU path) and the parent reports the failure — no hang, no JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: covered by tests/test_bench_cli.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "needs a GPU" in r.stderr

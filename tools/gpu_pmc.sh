@@ -5,11 +5,13 @@ R=$GRAFT_REPO_ROOT
 V=${V:-0}
 EXTRA=${EXTRA:-}
 TAG=${TAG:-v$V}
+# the real interpreter binary: nothing that re-execs may sit between rocprofv3's `--` and the program
+PYTHON=$(python3 -c 'import os, sys; print(os.path.realpath(sys.executable))')
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 5 --warmup 40 --variant $V --cpu-epochs 0 --no-live-traffic $EXTRA > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- $PYTHON $R/bench.py --steps 5 --warmup 40 --variant $V --cpu-epochs 0 --no-live-traffic $EXTRA > $OUT/$name.log 2>&1
 }
 run a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run b SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT

@@ -30,12 +30,13 @@ timeout 300 bash tools/gpu_zeros_probe.sh > $O/zeros_probe.txt 2>&1
 timeout 300 bash tools/gpu_power_probe.sh > $O/power_probe.txt 2>&1
 timeout 300 python tools/cpu_scaling.py > $O/cpu_scaling.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --cpu-epochs 0 --no-live-traffic --no-alt > $O/stats.log 2>&1
+PYTHON=$(python3 -c 'import os, sys; print(os.path.realpath(sys.executable))')   # the real binary: no launcher hop behind rocprofv3's `--`
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $PYTHON $R/bench.py --cpu-epochs 0 --no-live-traffic --no-alt > $O/stats.log 2>&1
 # HBM traffic per workload (FETCH_SIZE and WRITE_SIZE in separate passes)
 for cfgname in "headline:" "cfg1:--fft 1024" "cfg3:--mode ref" "cfg2:--mode welch" "e512:--fft 512" "e2048:--fft 2048" "unpruned:--variant 2"; do
   tag=${cfgname%%:*}; args=${cfgname#*:}
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- python3 $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_fetch_$tag.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- python3 $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_write_$tag.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- $PYTHON $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_fetch_$tag.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- $PYTHON $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_write_$tag.log 2>&1
 done
 cd $R
 # SQ / LDS / VMEM / GRBM counter groups per workload (tools/gpu_pmc.sh -> gpurun_out/pmc_<name>)
