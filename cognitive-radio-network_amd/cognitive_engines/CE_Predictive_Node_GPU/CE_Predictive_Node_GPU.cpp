@@ -15,6 +15,11 @@ static void die_crn(void) {
   exit(EXIT_FAILURE);
 }
 
+static void die_arg(const char *what, const char *value) {
+  fprintf(stderr, "CE_Predictive_Node_GPU: bad ce_args: %s '%s'\n", what, value ? value : "");
+  exit(EXIT_FAILURE);
+}
+
 // constructor (reference: CE_Predictive_Node.cpp:18-46).  Everything the engine will ever
 // allocate — tables, device batch buffers, pinned staging, the HIP stream — is allocated here,
 // and the kernels are loaded by one launch over zeros: execute() never allocates.
@@ -32,25 +37,79 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   sensing_on = 0;
   decision = 0;
   epochs_closed = 0;
+  epochs_calibrating = 0;
   packets_dropped = 0;
+  noise_floor = 0.f;
+  mode = MODE_REF;
+  epochs_per_batch = 1;
+  lambda = 4.0f;
+  calib_epochs = 8;
+  calib_have = 0;
   memset(features, 0, sizeof(features));
   memset(outputs, 0, sizeof(outputs));
-
-  crn_cfg_reference(&cfg);
+  memset(ch_bands, 0, sizeof(ch_bands));
+  memset(recent_decisions, 0, sizeof(recent_decisions));
 
   // ce_args from the scenario file arrive as argv (reference: src/crts.cpp:43-81 str2argcargv,
   // which resets optind; CE_Template.cpp:17-25 shows the getopt idiom)
   int o;
   optind = 1;
   stats_on = 0;
-  while ((o = getopt(argc, argv, "a:d:g:s:v:")) != EOF) {
+  int n_fft = 512, k_frames = 0, device = 0;
+  const char *weights = NULL;
+  while ((o = getopt(argc, argv, "a:b:c:d:g:k:m:n:s:t:v:w:")) != EOF) {
     switch (o) {
-    case 'a': async_mode = atoi(optarg); break;            // 0: decide inside the K-th execute()
-    case 'd': cfg.device = atoi(optarg); break;           // HIP device ordinal
+    case 'a': async_mode = atoi(optarg); break;            // 0: decide inside the epoch's last execute()
+    case 'b': epochs_per_batch = atoi(optarg); break;      // epochs per launch of the enqueue-only path
+    case 'c': calib_epochs = atoi(optarg); break;          // scan: noise-floor epochs
+    case 'd': device = atoi(optarg); break;                // HIP device ordinal
     case 'g': wall_clock_gate = atoi(optarg) != 0; break;  // 0: sense continuously
+    case 'k': k_frames = atoi(optarg); break;              // frames per decision
+    case 'm':
+      if (strcmp(optarg, "ref") == 0) mode = MODE_REF;
+      else if (strcmp(optarg, "energy") == 0) mode = MODE_ENERGY;
+      else if (strcmp(optarg, "welch") == 0) mode = MODE_WELCH;
+      else if (strcmp(optarg, "scan") == 0) mode = MODE_SCAN;
+      else die_arg("-m expects ref | energy | welch | scan, got", optarg);
+      break;
+    case 'n': n_fft = atoi(optarg); break;
     case 's': stats_on = atoi(optarg); break;               // 1: time every launch, one summary line at release()
+    case 't': lambda = (float)atof(optarg); break;
     case 'v': verbose = atoi(optarg); break;
+    case 'w': weights = optarg; break;
+    default: die_arg("unknown option", argv[optind > 0 ? optind - 1 : 0]);
     }
+  }
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048 && n_fft != 4096) die_arg("-n expects 512 | 1024 | 2048 | 4096", "");
+  if (k_frames < 0 || k_frames > 4096) die_arg("-k out of range", "");
+  if (epochs_per_batch < 1 || epochs_per_batch > 4096) die_arg("-b out of range", "");
+  if (!(lambda > 0.f)) die_arg("-t must be positive", "");
+  if (calib_epochs < 1 || calib_epochs > 4096) die_arg("-c out of range", "");
+  if (weights && mode != MODE_REF) die_arg("-w goes with -m ref, not with", "-m energy | welch | scan");
+
+  // the reference's constants (crn_cfg_reference), or the plan the arguments ask for
+  int rc = CRN_OK;
+  if (mode == MODE_REF) rc = crn_cfg_reference_scaled(&cfg, n_fft);
+  else if (mode == MODE_ENERGY) rc = crn_cfg_energy_scaled(&cfg, n_fft, lambda);
+  else if (mode == MODE_WELCH) rc = crn_cfg_welch_scaled(&cfg, n_fft, k_frames > 0 ? k_frames : 10, lambda);
+  else rc = crn_cfg_welch(&cfg, n_fft, k_frames > 0 ? k_frames : 8, 64);
+  if (rc != CRN_OK) die_crn();
+  if (k_frames > 0) cfg.frames_per_epoch = k_frames;
+  cfg.device = device;
+  if (weights && crn_cfg_load_ann(&cfg, weights) != CRN_OK) die_crn();
+  if (mode == MODE_REF && n_fft != 512 && !weights && verbose)
+    printf("CE_Predictive_Node_GPU: -n %d without -w: the reference's weights were fitted at 512 points\n", n_fft);
+  if (mode == MODE_SCAN) {
+    // which of the 64 equal bands lie on each channel: the reference's bin ranges (.cpp:173-191) at this FFT size
+    crn_cfg plan;
+    if (crn_cfg_reference_scaled(&plan, n_fft) != CRN_OK) die_crn();
+    const int w = n_fft / cfg.n_bands;
+    for (int s = 0; s < plan.n_segs; s++)
+      for (int k = plan.segs[s].lo; k < plan.segs[s].hi; k++)
+        if (plan.segs[s].band >= 1 && plan.segs[s].band <= 3) ch_bands[plan.segs[s].band][k / w] = 1;
+    calib_feat.assign((size_t)calib_epochs * cfg.n_bands, 0.f);
+  } else {
+    calib_have = calib_epochs = 0;
   }
 
   struct timeval tv;
@@ -62,13 +121,16 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   if (crn_sense_create(&cfg, &sensor) != CRN_OK) die_crn();
   if (crn_sense_reserve_host(sensor, 1, 0) != CRN_OK) die_crn();  // scratch + pinned staging + kernel load
   if (stats_on && crn_sense_set_timing(sensor, 1) != CRN_OK) die_crn();
+  frame_len = cfg.fft_len;
+  pad.assign((size_t)cfg.fft_len, std::complex<float>(0.f, 0.f));
   if (async_mode) {
-    // one stream, one epoch per batch; sized for full-length packets, the actual UHD packet length is
+    // one stream; sized for full-length packets, the actual UHD packet length is
     // known only when the rx worker starts (src/extensible_cognitive_radio.cpp:1263-1265)
-    if (crn_ingest_create(sensor, 1, cfg.fft_len, 1, &ring) != CRN_OK) die_crn();
-    frame_len = cfg.fft_len;
+    if (crn_ingest_create(sensor, 1, cfg.fft_len, epochs_per_batch, &ring) != CRN_OK) die_crn();
   } else {
-    staging.assign((size_t)cfg.frames_per_epoch * cfg.fft_len, std::complex<float>(0.f, 0.f));
+    // the longest run an epoch can need at any packet length: K packets of N (disjoint), span + one packet (overlapped)
+    const size_t span = (size_t)(cfg.frames_per_epoch - 1) * cfg.hop + cfg.fft_len;
+    staging.assign(cfg.hop == cfg.fft_len ? (size_t)cfg.frames_per_epoch * cfg.fft_len : span + cfg.fft_len, std::complex<float>(0.f, 0.f));
   }
 }
 
@@ -100,18 +162,72 @@ void CE_Predictive_Node_GPU::release() {
   sensor = NULL;
 }
 
+void CE_Predictive_Node_GPU::flush() {
+  if (!ring) return;
+  if (crn_ingest_drain(ring) != CRN_OK) die_crn();
+  crn_epoch_result r;
+  int32_t n = 0;
+  int rc;
+  while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_epoch(r.features, r.ann_out, r.decision, r.occupancy);
+  if (rc != CRN_OK) die_crn();
+}
+
+int CE_Predictive_Node_GPU::packets_in_epoch(int L) const {
+  if (cfg.hop == cfg.fft_len || L < 1) return cfg.frames_per_epoch;
+  const long span = (long)(cfg.frames_per_epoch - 1) * cfg.hop + cfg.fft_len;
+  return (int)((span + L - 1) / L);
+}
+
+// Threshold modes: the kernel reports per-band occupancy; the engine's decision keeps the reference's cascade order
+// (.cpp:245-258: CH1 first, then CH2, then CH3; at most one channel is ever reported).
+int CE_Predictive_Node_GPU::channel_decision(const unsigned char *occ) const {
+  for (int k = 1; k <= 3; k++) {
+    if (mode != MODE_SCAN) {
+      if (occ[k]) return k;      // bands are {NF, CH1, CH2, CH3}
+    } else {
+      for (int b = 0; b < cfg.n_bands; b++)
+        if (ch_bands[k][b] && occ[b]) return k;
+    }
+  }
+  return 0;
+}
+
+// One epoch's results, from either path: scan-mode calibration first, then the reference's report + action block.
+void CE_Predictive_Node_GPU::close_epoch(const float *feat, const double *out3, int kernel_decision, const unsigned char *occupancy) {
+  if (calib_have < calib_epochs) {
+    // scan mode, start-up: the thresholds are lambda x the measured noise floor (NF_est = the median band
+    // energy), so the first epochs only feed the estimate.  The last of them pays for one blocking upload + reduction + update.
+    memcpy(&calib_feat[(size_t)calib_have * cfg.n_bands], feat, sizeof(float) * (size_t)cfg.n_bands);
+    epochs_calibrating++;
+    if (++calib_have == calib_epochs) {
+      if (crn_noise_floor_host(sensor, calib_feat.data(), calib_epochs, &noise_floor) != CRN_OK) die_crn();
+      for (int b = 0; b < cfg.n_bands; b++) cfg.thresh[b] = lambda * noise_floor;
+      if (crn_sense_set_thresholds(sensor, cfg.thresh, cfg.n_bands, NULL) != CRN_OK) die_crn();
+      if (crn_sense_synchronize(sensor, NULL) != CRN_OK) die_crn();   // the ring launches on a stream of its own
+      if (verbose) printf("CE_Predictive_Node_GPU: noise floor %.4e per band over %d epochs, threshold %.4e\n", noise_floor, calib_epochs, cfg.thresh[0]);
+    }
+    return;
+  }
+  const int d = mode == MODE_REF ? kernel_decision : channel_decision(occupancy);
+  report(feat, out3, d);
+}
+
 // The reference's report + action block (.cpp:202-261) for one closed epoch.
 void CE_Predictive_Node_GPU::report(const float *feat, const double *out3, int d) {
-  memcpy(features, feat, sizeof(features));
+  memcpy(features, feat, sizeof(float) * (size_t)cfg.n_bands);
   memcpy(outputs, out3, sizeof(outputs));
   decision = d;
+  recent_decisions[epochs_closed % 64] = d;
   epochs_closed++;
   if (verbose) {  // .cpp:202-207, 239-241
     printf("--------------------------------------------------------------\n");
     printf("-            		FEATURES BUFFER 	               -\n");
     printf("--------------------------------------------------------------\n");
-    printf("NOISE FLOOR   %.2e\nCH1           %.2e\nCH2           %.2e\nCH3           %.2e\n ", features[0],
-           features[1], features[2], features[3]);
+    if (mode != MODE_SCAN)
+      printf("NOISE FLOOR   %.2e\nCH1           %.2e\nCH2           %.2e\nCH3           %.2e\n ", features[0],
+             features[1], features[2], features[3]);
+    else
+      printf("%d bands, noise floor %.2e, threshold %.2e\n ", cfg.n_bands, noise_floor, cfg.thresh[0]);
     printf("\n \n \n --------------------------------------------------------------\n");
     printf("-            		 REAL TIME PREDICTION                  -\n");
     printf("--------------------------------------------------------------\n");
@@ -154,37 +270,49 @@ void CE_Predictive_Node_GPU::execute() {
     sensing_on = 1;
   }
 
-  // a decision launched by an earlier call may have landed (one event query, never a wait)
+  // a decision launched by an earlier call may have landed (one event query, never a wait).  A launch or device failure on
+  // the ring's launcher thread is reported here and nowhere else: it ends the run like the same failure in the
+  // synchronous form does (the reference's convention: printf + exit, src/crts.cpp:111-115).
   if (ring) {
     crn_epoch_result r;
     int32_t n = 0;
-    while (crn_ingest_poll(ring, &r, 1, &n) == CRN_OK && n == 1) report(r.features, r.ann_out, r.decision);
+    int rc;
+    while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_epoch(r.features, r.ann_out, r.decision, r.occupancy);
+    if (rc != CRN_OK) die_crn();
   }
 
   // handle samples (.cpp:146)
   if (ECR->CE_metrics.CE_event == ExtensibleCognitiveRadio::USRP_RX_SAMPS) {
-    const int N = cfg.fft_len, K = cfg.frames_per_epoch;
+    const int N = cfg.fft_len;
     // .cpp:149 copies ce_usrp_rx_buffer_length samples unchecked; a packet longer than the FFT
     // would overrun the reference's buffer — here it is truncated to N.
     int L = ECR->ce_usrp_rx_buffer_length;
     if (L > N) L = N;
     if (L < 1) return;
+    const std::complex<float> *pkt = ECR->ce_usrp_rx_buffer;
     if (ring) {
-      if (L != frame_len) {              // UHD packet size is constant in practice: once, at the first packet
-        if (fft_counter != 0) return;    // never inside an epoch
+      if (L != frame_len && fft_counter == 0) {   // UHD packet size is constant in practice: once, at the first packet
         const int rc = crn_ingest_set_packet_len(ring, L);
         if (rc == CRN_ERR_BUSY) { packets_dropped++; return; }
         if (rc != CRN_OK) die_crn();
         frame_len = L;
       }
-      // one copy of the packet into its pinned slot; the K-th one also enqueues H2D + kernel + D2H
-      const int rc = crn_ingest_push(ring, 0, reinterpret_cast<const float *>(ECR->ce_usrp_rx_buffer));
+      if (L != frame_len) {
+        // a different length INSIDE an epoch: the epoch keeps its length — the packet is truncated or zero-padded to it, as
+        // the synchronous form does (never dropped: a run of such packets must not stall the epoch, and with it sensing)
+        const int n = L < frame_len ? L : frame_len;
+        memcpy(pad.data(), pkt, (size_t)n * sizeof(std::complex<float>));
+        for (int i = n; i < frame_len; i++) pad[i] = std::complex<float>(0.f, 0.f);
+        pkt = pad.data();
+      }
+      // one copy of the packet into its pinned slot; the epoch's last one also enqueues H2D + kernel + D2H
+      const int rc = crn_ingest_push(ring, 0, reinterpret_cast<const float *>(pkt));
       if (rc == CRN_ERR_BUSY) {          // both batch buffers on the GPU: this packet is skipped, like a
         packets_dropped++;               // frame the reference's CE thread was not ready for
         return;
       }
       if (rc != CRN_OK) die_crn();
-      if (++fft_counter == K) {
+      if (++fft_counter == packets_in_epoch(frame_len)) {
         ECR->set_ce_sensing(0);  // .cpp:159; the decision is reported by a later execute()
         sensing_on = 0;
         fft_counter = 0;         // .cpp:287-288
@@ -194,11 +322,12 @@ void CE_Predictive_Node_GPU::execute() {
     if (fft_counter == 0) frame_len = L;
     if (L != frame_len) L = L < frame_len ? L : frame_len;  // UHD packet size is constant in practice
     std::complex<float> *dst = &staging[(size_t)fft_counter * frame_len];
-    memcpy(dst, ECR->ce_usrp_rx_buffer, (size_t)L * sizeof(std::complex<float>));
+    memcpy(dst, pkt, (size_t)L * sizeof(std::complex<float>));
     for (int i = L; i < frame_len; i++) dst[i] = std::complex<float>(0.f, 0.f);
     fft_counter++;
 
-    if (fft_counter == K) {  // .cpp:157
+    const int P = packets_in_epoch(frame_len);
+    if (fft_counter == P) {  // .cpp:157
       ECR->set_ce_sensing(0);  // .cpp:159
       sensing_on = 0;
 
@@ -206,15 +335,18 @@ void CE_Predictive_Node_GPU::execute() {
       crn_out out;
       memset(&out, 0, sizeof(out));
       int32_t d = 0;
-      float feat[4];
-      double out3[3];
+      float feat[CRN_MAX_BANDS];
+      unsigned char occ[CRN_MAX_BANDS];
+      double out3[3] = {0.0, 0.0, 0.0};
       out.features = feat;
       out.ann_out = out3;
       out.decision = &d;
-      if (crn_sense_run_host(sensor, reinterpret_cast<const float *>(staging.data()), 1, frame_len, 0, &out) !=
-          CRN_OK)
+      out.occupancy = occ;
+      const bool overlapped = cfg.hop != cfg.fft_len;   // Welch: whole frames cut from the run of P packets
+      if (crn_sense_run_host(sensor, reinterpret_cast<const float *>(staging.data()), 1, overlapped ? N : frame_len,
+                             overlapped ? (int64_t)P * frame_len : 0, &out) != CRN_OK)
         die_crn();
-      report(feat, out3, d);
+      close_epoch(feat, out3, d, occ);
 
       fft_counter = 0;  // .cpp:287-288 (fft_avg lives on the device and starts from zero each launch)
     }

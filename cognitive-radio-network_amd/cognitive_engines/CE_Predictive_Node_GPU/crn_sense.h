@@ -144,6 +144,19 @@ typedef struct crn_out {
  * weights of .cpp:78-120, threshold 0.8, tx map 835e6/833e6/835e6 (.hpp:55-57, .cpp:245-258). */
 CRN_API int crn_cfg_reference(crn_cfg *cfg);
 
+/* The reference engine's estimator at another FFT size: crn_cfg_reference with fft_len N (multiple of 512) and the five bin
+ * ranges scaled by N/512 (the same frequency spans at fs = 13 MHz); REF_MAG + DECIDE_ANN.  The weights stay the reference's,
+ * which were fitted at N = 512 and one receiver gain (features grow with N^2): fit others with crn_ann_train_device and put
+ * them in with crn_cfg_load_ann / crn_sense_set_ann. */
+CRN_API int crn_cfg_reference_scaled(crn_cfg *cfg, int32_t fft_len);
+
+/* The 4-5-3 network's weights as a text file — what crn_ann_train_device produces, for an engine's `-w <file>` (ce_args:
+ * src/crts.cpp:43-81): '#' comments, then WeightIH[5][6] and WeightHO[6][4] in the reference's array order
+ * (CE_Predictive_Node.hpp:66,71; .cpp:78-120), then optionally the decision threshold.  Doubles are written with 17 digits
+ * (exact round trip).  load leaves everything else in cfg untouched. */
+CRN_API int crn_cfg_save_ann(const crn_cfg *cfg, const char *path);
+CRN_API int crn_cfg_load_ann(crn_cfg *cfg, const char *path);
+
 /* Build-side generalisation used by BASELINE.json configs[1] and the headline metric:
  * fft_len N (multiple of 512), K=10, rectangular, ENERGY, the reference's bin ranges scaled by
  * N/512 (same frequency spans at fs = 13 MHz), DECIDE_THRESHOLD relative to the noise-floor band
@@ -154,6 +167,9 @@ CRN_API int crn_cfg_energy_scaled(crn_cfg *cfg, int32_t fft_len, float lambda);
  * contiguous bands covering all N bins, absolute thresholds (ref_band = -1) to be filled in by
  * the caller in cfg->thresh. */
 CRN_API int crn_cfg_welch(crn_cfg *cfg, int32_t fft_len, int32_t frames_per_epoch, int32_t n_bands);
+
+/* crn_cfg_energy_scaled's channel plan and relative thresholds on a Welch estimate: periodic Hann, hop N/2, K frames. */
+CRN_API int crn_cfg_welch_scaled(crn_cfg *cfg, int32_t fft_len, int32_t frames_per_epoch, float lambda);
 
 /* -- lifecycle --------------------------------------------------------------------------- */
 
@@ -236,8 +252,12 @@ typedef struct crn_epoch_result {
   uint8_t occupancy[CRN_MAX_BANDS];
 } crn_epoch_result;
 
-/* samples_per_packet: L of every pushed packet (1..fft_len; disjoint frames only) — also the largest
+/* samples_per_packet: L of every pushed packet (1..fft_len) — also the largest
  * L crn_ingest_set_packet_len may select later (buffers are sized for it here, once).
+ * Disjoint frames (hop == fft_len, the reference's shape): a packet is a frame, zero-padded to fft_len by the kernel; K packets
+ * make an epoch.  Overlapped frames (hop < fft_len, the Welch plans): the packets of an epoch are consecutive pieces of ONE
+ * contiguous run of samples, ceil(((K - 1) hop + fft_len) / L) of them (crn_ingest_packets_per_epoch), from which the kernel
+ * cuts its K overlapped frames.
  * epochs_per_batch: completed epochs that trigger a launch.  All device, pinned and host memory the
  * ring will ever use is allocated by this call. */
 CRN_API int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet,
@@ -267,7 +287,9 @@ CRN_API int crn_ingest_wait(crn_ingest *g);
 CRN_API int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, int32_t *n_out);
 /* flush + wait for everything in flight (results stay queued for crn_ingest_poll). */
 CRN_API int crn_ingest_drain(crn_ingest *g);
-/* Packets refused with CRN_ERR_BUSY so far. */
+/* Packets that complete an epoch at the current packet length: K for disjoint frames, see crn_ingest_create for overlapped ones. */
+CRN_API int crn_ingest_packets_per_epoch(crn_ingest *g, int32_t *n_packets);
+/* Packets refused with CRN_ERR_BUSY so far (a caller that waits and pushes again has each such packet counted once per refusal). */
 CRN_API int crn_ingest_dropped(crn_ingest *g, int64_t *n_packets);
 /* Counters of a ring since its creation (the operational view the reference has only as printf lines: SURVEY.md §8b proposed
  * `crn_sense_stats`).  Never blocks; call from the thread that pushes. */
@@ -308,16 +330,25 @@ typedef struct crn_comm crn_comm;
 
 CRN_API int crn_comm_unique_id(uint8_t id[CRN_COMM_ID_BYTES]);
 /* Collective over all `world` ranks (blocks until every rank has called it).  Allocates, once, the
- * `depth` local and gathered slots on `device` and a private side stream. */
+ * `depth` local and gathered slots on `device` and a private side stream.  Like ncclCommInitRank itself it cannot tell the
+ * other ranks about a local failure: if this call fails on one rank (bad argument, no memory, RCCL missing) the others stay
+ * inside the collective, so the launcher must take the job down — torch.distributed.run does; a caller with a control
+ * plane of its own should first agree that every rank can load RCCL (crn_comm_unique_id into a scratch id is a
+ * non-collective probe: bench.py / sharding.py do exactly that). */
 CRN_API int crn_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[CRN_COMM_ID_BYTES],
                             int64_t bytes_per_rank, int32_t depth, crn_comm **out);
 /* Device address of the block step `step` writes (slot step % depth).  If that slot's previous gather
  * is still in flight, `stream` is made to wait for it (on the device; the host does not block). */
 CRN_API int crn_comm_local(crn_comm *c, int64_t step, void *stream, uint8_t **d_local);
+/* The same address without touching the slot's state or any stream (for reading the block back, say). */
+CRN_API int crn_comm_local_addr(crn_comm *c, int64_t step, uint8_t **d_local);
 /* Queue the all-gather of step `step`'s block behind everything enqueued on `stream` so far.  Only enqueues. */
 CRN_API int crn_comm_allgather(crn_comm *c, int64_t step, void *stream);
 /* Device address of step `step`'s gathered vector, [world][bytes_per_rank], rank order. */
 CRN_API int crn_comm_gathered(crn_comm *c, int64_t step, const uint8_t **d_all);
+/* Make `stream` wait for step `step`'s gather alone (work queued on `stream` after the call may read crn_comm_gathered(step)).
+ * The slot stays marked in flight: whichever stream later takes it through crn_comm_local, or calls crn_comm_finish, still waits. */
+CRN_API int crn_comm_wait(crn_comm *c, int64_t step, void *stream);
 /* Make `stream` wait for every gather queued so far (call before the final synchronise). */
 CRN_API int crn_comm_finish(crn_comm *c, void *stream);
 CRN_API int crn_comm_destroy(crn_comm *c);
@@ -454,6 +485,24 @@ CRN_API int crn_noise_floor_device(crn_handle *h, const float *d_features, int64
  * after the call see the new values, launches before it the old ones.  `thresh` is read before the call returns. */
 CRN_API int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream);
 
+/* The same estimate from a features matrix in host memory (an engine that keeps no device buffers of its own): uploaded, then
+ * crn_noise_floor_device.  Blocking; not for the packet path. */
+CRN_API int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs, float *nf_out);
+/* Replace the network of a DECIDE_ANN handle (cfg.ann_w_ih / ann_w_ho / ann_threshold; the reference has its weights as
+ * literals, CE_Predictive_Node.cpp:78-120): ordered on `stream` like crn_sense_set_thresholds.  The threshold rides in the launch
+ * parameters: launches made after the call use it. */
+CRN_API int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[6][4], double threshold, void *stream);
+/* Replace the band plan of a live handle (cfg.segs / n_segs / n_bands; the reference's is the five loops of
+ * CE_Predictive_Node.cpp:173-191).  thresh: n_bands new thresholds, or NULL to keep the current ones (then n_bands must not
+ * change).  Same validation as crn_sense_create.  Every table derived from the plan is rebuilt into a fresh allocation and the
+ * call waits for launches in flight on the device before it frees the old one: not for the packet path.  Ingest rings size their
+ * result buffers for the n_bands they were created with: create them after a call that changes n_bands. */
+CRN_API int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs, int32_t n_bands, const float *thresh);
+
+/* Wait until everything queued on `stream` (NULL = the default stream) of the handle's device has completed: for callers that are
+ * pure host code against this ABI (the engine) and need an asynchronous update to have landed before they go on. */
+CRN_API int crn_sense_synchronize(crn_handle *h, void *stream);
+
 /* Counters of a sensing handle since its creation.  `samples` counts every input sample a launch covers once (8 bytes each: the
  * algorithmic read of the path), so samples * 8 / kernel seconds is the same figure bench.py's roofline reports.  Durations are
  * measured only while crn_sense_set_timing(h, 1) is in effect (two HIP events per launch on the launch stream, a ring of 16 pairs;
@@ -479,6 +528,12 @@ CRN_API int crn_sense_set_variant(crn_handle *h, int32_t variant);
 
 CRN_API const char *crn_last_error(void);
 CRN_API int crn_abi_version(void);
+/* Toolchain contract.  built_hip: HIP_VERSION of the headers the library was compiled with (major * 10^7 + minor * 10^5 + patch);
+ * runtime_hip: what hipRuntimeGetVersion reports on this machine (0 when no runtime answers).  The library links libamdhip64.so.<major>
+ * and carries a gfx950 code object only: it runs on any ROCm whose HIP runtime has the SAME MAJOR version as built_hip and is not
+ * older than ROCm 7.0 (the first release with gfx950).  Returns CRN_OK when that holds, CRN_ERR_STATE (with the two versions in
+ * crn_last_error) when it does not.  Either pointer may be NULL. */
+CRN_API int crn_build_info(int32_t *built_hip, int32_t *runtime_hip);
 
 #ifdef __cplusplus
 }

@@ -24,19 +24,20 @@ WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 
 # every symbol include/crn_sense.h declares (tests check the library exports them all)
 EXPORTS = [
-    "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch",
+    "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch", "crn_cfg_reference_scaled", "crn_cfg_welch_scaled",
+    "crn_cfg_save_ann", "crn_cfg_load_ann", "crn_sense_set_ann", "crn_sense_set_bands", "crn_noise_floor_host", "crn_sense_synchronize",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
     "crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
-    "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped",
+    "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped", "crn_ingest_packets_per_epoch",
     "crn_noise_floor_device", "crn_sense_set_thresholds",
     "crn_sense_reserve_host", "crn_sense_set_timing", "crn_sense_get_stats", "crn_ingest_get_stats",
     "crn_monitor_rows_device",
     "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
-    "crn_comm_finish", "crn_comm_destroy",
-    "crn_last_error", "crn_abi_version",
+    "crn_comm_finish", "crn_comm_destroy", "crn_comm_local_addr", "crn_comm_wait",
+    "crn_last_error", "crn_abi_version", "crn_build_info",
 ]
 
 
@@ -120,9 +121,18 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         L.crn_last_error.restype = C.c_char_p
+        L.crn_build_info.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_cfg_reference.argtypes = [C.POINTER(Cfg)]
         L.crn_cfg_energy_scaled.argtypes = [C.POINTER(Cfg), C.c_int32, C.c_float]
         L.crn_cfg_welch.argtypes = [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32]
+        L.crn_cfg_reference_scaled.argtypes = [C.POINTER(Cfg), C.c_int32]
+        L.crn_cfg_welch_scaled.argtypes = [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_float]
+        L.crn_cfg_save_ann.argtypes = [C.POINTER(Cfg), C.c_char_p]
+        L.crn_cfg_load_ann.argtypes = [C.POINTER(Cfg), C.c_char_p]
+        L.crn_sense_set_ann.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.crn_sense_set_bands.argtypes = [C.c_void_p, C.POINTER(BandSeg), C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+        L.crn_sense_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        L.crn_noise_floor_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float)]
         L.crn_sense_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_void_p)]
         L.crn_sense_destroy.argtypes = [C.c_void_p]
         L.crn_sense_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
@@ -155,6 +165,7 @@ def lib():
         L.crn_ingest_set_packet_len.argtypes = [C.c_void_p, C.c_int32]
         L.crn_ingest_wait.argtypes = [C.c_void_p]
         L.crn_ingest_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.crn_ingest_packets_per_epoch.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.crn_noise_floor_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.crn_sense_set_thresholds.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p]
@@ -168,11 +179,20 @@ def lib():
                                       C.POINTER(C.c_void_p)]
         L.crn_comm_local.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]
         L.crn_comm_allgather.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.crn_comm_local_addr.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.crn_comm_wait.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.crn_comm_gathered.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.crn_comm_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.crn_comm_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def build_info():
+    """(built_hip, runtime_hip, compatible): HIP_VERSION the library was compiled with, the runtime's, and crn_build_info's verdict."""
+    b, r = C.c_int32(), C.c_int32()
+    rc = lib().crn_build_info(C.byref(b), C.byref(r))
+    return b.value, r.value, rc == 0
 
 
 def check(rc, what):
@@ -190,6 +210,27 @@ def cfg_energy_scaled(fft_len, lam=4.0):
     c = Cfg()
     check(lib().crn_cfg_energy_scaled(C.byref(c), fft_len, lam), "crn_cfg_energy_scaled")
     return c
+
+
+def cfg_reference_scaled(fft_len):
+    c = Cfg()
+    check(lib().crn_cfg_reference_scaled(C.byref(c), fft_len), "crn_cfg_reference_scaled")
+    return c
+
+
+def cfg_welch_scaled(fft_len, frames_per_epoch=8, lam=4.0):
+    c = Cfg()
+    check(lib().crn_cfg_welch_scaled(C.byref(c), fft_len, frames_per_epoch, lam), "crn_cfg_welch_scaled")
+    return c
+
+
+def save_ann(cfg, path):
+    check(lib().crn_cfg_save_ann(C.byref(cfg), os.fsencode(path)), "crn_cfg_save_ann")
+
+
+def load_ann(cfg, path):
+    check(lib().crn_cfg_load_ann(C.byref(cfg), os.fsencode(path)), "crn_cfg_load_ann")
+    return cfg
 
 
 def cfg_welch(fft_len, frames_per_epoch, n_bands):
@@ -248,6 +289,34 @@ class Sensor:
         check(lib().crn_sense_set_thresholds(self._h, arr, len(thresh), stream), "crn_sense_set_thresholds")
         for b, t in enumerate(arr):
             self.cfg.thresh[b] = t
+
+    def set_ann(self, w_ih, w_ho, threshold=0.8, stream=0):
+        """Replace the network of a DECIDE_ANN handle (ordered on `stream`); also updates self.cfg."""
+        import numpy as np
+        a, b = np.ascontiguousarray(w_ih, np.float64), np.ascontiguousarray(w_ho, np.float64)
+        assert a.shape == (5, 6) and b.shape == (6, 4)
+        check(lib().crn_sense_set_ann(self._h, a.ctypes.data, b.ctypes.data, threshold, C.c_void_p(stream or None)), "crn_sense_set_ann")
+        set_ann_weights(self.cfg, a, b, threshold)
+
+    def set_bands(self, segs, n_bands, thresh=None):
+        """Replace the band plan of the live handle: segs = [(lo, hi, band), ..]; thresh = n_bands floats or None (keep)."""
+        arr = (BandSeg * len(segs))(*[BandSeg(int(lo), int(hi), int(b)) for lo, hi, b in segs])
+        th = None if thresh is None else (C.c_float * n_bands)(*[float(t) for t in thresh])
+        check(lib().crn_sense_set_bands(self._h, arr, len(segs), n_bands, th), "crn_sense_set_bands")
+        self.cfg.n_segs, self.cfg.n_bands = len(segs), n_bands
+        for i, sg in enumerate(arr):
+            self.cfg.segs[i] = sg
+        if th is not None:
+            for b in range(n_bands):
+                self.cfg.thresh[b] = th[b]
+
+    def noise_floor_host(self, features):
+        """crn_noise_floor_host on a numpy [n_epochs][n_bands] float32 matrix."""
+        import numpy as np
+        f = np.ascontiguousarray(features, np.float32)
+        nf = C.c_float()
+        check(lib().crn_noise_floor_host(self._h, f.ctypes.data, f.shape[0], C.byref(nf)), "crn_noise_floor_host")
+        return nf.value
 
     def set_timing(self, on=True):
         check(lib().crn_sense_set_timing(self._h, 1 if on else 0), "crn_sense_set_timing")
@@ -386,6 +455,16 @@ class Comm:
         check(lib().crn_comm_local(self._c, step, C.c_void_p(stream or None), C.byref(p)), "crn_comm_local")
         return p.value
 
+    def local_addr(self, step):
+        """The slot's address, without making any stream wait or releasing the slot."""
+        p = C.c_void_p()
+        check(lib().crn_comm_local_addr(self._c, step, C.byref(p)), "crn_comm_local_addr")
+        return p.value
+
+    def wait(self, step, stream=0):
+        """Make `stream` wait for step's gather only; the slot stays in flight for local() / finish()."""
+        check(lib().crn_comm_wait(self._c, step, C.c_void_p(stream or None)), "crn_comm_wait")
+
     def allgather(self, step, stream=0):
         check(lib().crn_comm_allgather(self._c, step, C.c_void_p(stream or None)), "crn_comm_allgather")
 
@@ -433,6 +512,11 @@ class Ingest:
         st = IngestStats()
         check(lib().crn_ingest_get_stats(self._g, C.byref(st)), "crn_ingest_get_stats")
         return {k: getattr(st, k) for k, _ in IngestStats._fields_}
+
+    def packets_per_epoch(self):
+        n = C.c_int32()
+        check(lib().crn_ingest_packets_per_epoch(self._g, C.byref(n)), "crn_ingest_packets_per_epoch")
+        return n.value
 
     def dropped(self):
         n = C.c_int64()

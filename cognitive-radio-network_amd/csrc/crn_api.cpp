@@ -104,26 +104,14 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-extern "C" {
-
-const char *crn_last_error(void) { return crn::g_err.c_str(); }
-int crn_abi_version(void) { return CRN_ABI_VERSION; }
-
-int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
-  if (!out) return crn::fail(CRN_ERR_ARG, "crn_sense_create: null out");
-  *out = nullptr;
-  if (int rc = validate(cfg)) return rc;
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev < 1) return crn::fail(CRN_ERR_DEVICE, "no HIP device visible (libcrnsense has no CPU path)");
-  if (cfg->device < 0 || cfg->device >= ndev) return crn::fail(CRN_ERR_ARG, "cfg.device out of range");
-  HIP_TRY(hipSetDevice(cfg->device));
-
-  crn_handle *h = new (std::nothrow) crn_handle();
-  if (!h) return crn::fail(CRN_ERR_NOMEM, "out of host memory");
-  h->cfg = *cfg;
-
-  const int N = cfg->fft_len, R3 = N / 256, T = N / 16;
+// Everything a handle keeps in HBM for its configuration, built from h->cfg into one fresh slab (crn_sense_create, and again by
+// crn_sense_set_bands on a live handle): twiddles, window, the band plan in its three forms, thresholds, ANN weights.
+static int build_tables(crn_handle *h) {
+  const crn_cfg &cfg = h->cfg;
+  h->window_power = 0.0;
+  h->aligned_shift = 0;
+  h->row_mask = 0xFFFFu;
+  const int N = cfg.fft_len, R3 = N / 256, T = N / 16;
   std::vector<float2> tw1((size_t)17 * T), tw2((size_t)16 * R3);  // row 16 of tw1: W_N^{16 t}
   for (int i = 0; i < 16; i++)
     for (int t = 0; t < T; t++) tw1[(size_t)i * T + t] = twiddle((long long)i * t, N);
@@ -131,9 +119,9 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   for (int i = 0; i < 16; i++)
     for (int m = 0; m < R3; m++) tw2[(size_t)i * R3 + m] = twiddle((long long)i * m, T);
   std::vector<float> win(N, 1.0f);
-  if (cfg->window == CRN_WINDOW_HANN)
+  if (cfg.window == CRN_WINDOW_HANN)
     for (int n = 0; n < N; n++) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)N));
-  if (cfg->window == CRN_WINDOW_BLACKMAN_HARRIS)
+  if (cfg.window == CRN_WINDOW_BLACKMAN_HARRIS)
     for (int n = 0; n < N; n++) {
       const double x = 2.0 * M_PI * (double)n / (double)(N - 1);
       win[n] = (float)(0.35875 - 0.48829 * std::cos(x) + 0.14128 * std::cos(2 * x) - 0.01168 * std::cos(3 * x));
@@ -143,31 +131,31 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
 
   // segments grouped by band, table order kept inside a band (the reference sums CH1's two runs
   // in table order, CE_Predictive_Node.cpp:173-179)
-  std::vector<int> seg_begin(cfg->n_bands + 1, 0), seg_lo, seg_hi, bins_begin(cfg->n_bands + 1, 0), bins;
-  for (int b = 0; b < cfg->n_bands; b++) {
+  std::vector<int> seg_begin(cfg.n_bands + 1, 0), seg_lo, seg_hi, bins_begin(cfg.n_bands + 1, 0), bins;
+  for (int b = 0; b < cfg.n_bands; b++) {
     seg_begin[b] = (int)seg_lo.size();
     bins_begin[b] = (int)bins.size();
-    for (int s = 0; s < cfg->n_segs; s++)
-      if (cfg->segs[s].band == b) {
-        seg_lo.push_back(cfg->segs[s].lo);
-        seg_hi.push_back(cfg->segs[s].hi);
-        for (int k = cfg->segs[s].lo; k < cfg->segs[s].hi; k++) bins.push_back(k);
+    for (int s = 0; s < cfg.n_segs; s++)
+      if (cfg.segs[s].band == b) {
+        seg_lo.push_back(cfg.segs[s].lo);
+        seg_hi.push_back(cfg.segs[s].hi);
+        for (int k = cfg.segs[s].lo; k < cfg.segs[s].hi; k++) bins.push_back(k);
       }
   }
   if (N == 4096) {
     h->row_mask = 0;
-    for (int sgi = 0; sgi < cfg->n_segs; sgi++)
-      for (int k = cfg->segs[sgi].lo; k < cfg->segs[sgi].hi; k++) h->row_mask |= 1u << (k >> 8);
+    for (int sgi = 0; sgi < cfg.n_segs; sgi++)
+      for (int k = cfg.segs[sgi].lo; k < cfg.segs[sgi].hi; k++) h->row_mask |= 1u << (k >> 8);
   }
-  if (N == 4096 && cfg->n_segs == cfg->n_bands && N % cfg->n_bands == 0 && cfg->decide != CRN_DECIDE_ANN) {
-    const int W = N / cfg->n_bands;
+  if (N == 4096 && cfg.n_segs == cfg.n_bands && N % cfg.n_bands == 0 && cfg.decide != CRN_DECIDE_ANN) {
+    const int W = N / cfg.n_bands;
     bool ok = W == 64 || W == 128 || W == 256;
-    for (int b = 0; ok && b < cfg->n_bands; b++)
-      ok = cfg->segs[b].band == b && cfg->segs[b].lo == b * W && cfg->segs[b].hi == (b + 1) * W;
+    for (int b = 0; ok && b < cfg.n_bands; b++)
+      ok = cfg.segs[b].band == b && cfg.segs[b].lo == b * W && cfg.segs[b].hi == (b + 1) * W;
     if (ok) h->aligned_shift = W == 64 ? 6 : W == 128 ? 7 : 8;
   }
-  seg_begin[cfg->n_bands] = (int)seg_lo.size();
-  bins_begin[cfg->n_bands] = (int)bins.size();
+  seg_begin[cfg.n_bands] = (int)seg_lo.size();
+  bins_begin[cfg.n_bands] = (int)bins.size();
   if (bins.empty()) bins.push_back(0);
 
   // packed band table for the kernel's LDS copy (layout: crn_kernels.h)
@@ -177,9 +165,9 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     band_tab[96 + i] = seg_lo[i];
     band_tab[256 + i] = seg_hi[i];
   }
-  std::memcpy(&band_tab[416], cfg->thresh, sizeof(float) * CRN_MAX_BANDS);
-  std::memcpy(&band_tab[544], cfg->ann_w_ih, sizeof(cfg->ann_w_ih));  // 30 doubles
-  std::memcpy(&band_tab[604], cfg->ann_w_ho, sizeof(cfg->ann_w_ho));  // 24 doubles
+  std::memcpy(&band_tab[416], cfg.thresh, sizeof(float) * CRN_MAX_BANDS);
+  std::memcpy(&band_tab[544], cfg.ann_w_ih, sizeof(cfg.ann_w_ih));  // 30 doubles
+  std::memcpy(&band_tab[604], cfg.ann_w_ho, sizeof(cfg.ann_w_ho));  // 24 doubles
   // Row entries for the register-resident band sums (epoch_close): every thread's accumulators sit
   // at bins base + 256 d, so a segment is cut at the 256-bin rows and each piece becomes
   // (row d, band, [lo, hi) inside the row), grouped by row, band-table order kept inside a row.
@@ -188,7 +176,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   {
     struct Piece { int d, band, lo, hi; };
     std::vector<Piece> pieces;
-    for (int b = 0; b < cfg->n_bands; b++)
+    for (int b = 0; b < cfg.n_bands; b++)
       for (int sg = seg_begin[b]; sg < seg_begin[b + 1]; sg++)
         for (int d = seg_lo[sg] >> 8; seg_lo[sg] < seg_hi[sg] && d <= (seg_hi[sg] - 1) >> 8; d++) {
           const int lo = std::max(seg_lo[sg], 256 * d) - 256 * d, hi = std::min(seg_hi[sg], 256 * (d + 1)) - 256 * d;
@@ -197,7 +185,7 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     // fixed layout, no walk: row d owns words [512 + d * cap, 512 + (d + 1) * cap), cap = 32 / R3;
     // an unused slot is 0 (span 0)
     const int cap = crn::kRowEntryWords / R3;
-    bool fits = cfg->n_bands <= 16 && !pieces.empty();
+    bool fits = cfg.n_bands <= 16 && !pieces.empty();
     std::vector<int> used(16, 0);
     for (const Piece &pc : pieces)
       if (++used[pc.d] > cap) fits = false;
@@ -211,8 +199,8 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   // twice the signed centre of every band (bins >= N / 2 are negative frequencies; lowest + highest signed bin, so a band with a
   // small gap in it — the reference plan's CH1 skips bins -1, -2 — is centred on its span): the carrier of the generator's
   // modulated signal kinds
-  std::vector<int> band_c2(std::max(cfg->n_bands, 1), 0);
-  for (int b = 0; b < cfg->n_bands; b++) {
+  std::vector<int> band_c2(std::max(cfg.n_bands, 1), 0);
+  for (int b = 0; b < cfg.n_bands; b++) {
     int lo = N, hi = -N;
     for (int i = bins_begin[b]; i < bins_begin[b + 1]; i++) {
       const int k = bins[i] >= N / 2 ? bins[i] - N : bins[i];
@@ -227,14 +215,14 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
       {tw1.data(), tw1.size() * sizeof(float2), 0},
       {tw2.data(), tw2.size() * sizeof(float2), 0},
       {win.data(), win.size() * sizeof(float), 0},
-      {cfg->thresh, sizeof(float) * CRN_MAX_BANDS, 0},
+      {cfg.thresh, sizeof(float) * CRN_MAX_BANDS, 0},
       {seg_begin.data(), seg_begin.size() * sizeof(int), 0},
       {seg_lo.data(), seg_lo.size() * sizeof(int), 0},
       {seg_hi.data(), seg_hi.size() * sizeof(int), 0},
       {bins_begin.data(), bins_begin.size() * sizeof(int), 0},
       {bins.data(), bins.size() * sizeof(int), 0},
-      {cfg->ann_w_ih, sizeof(cfg->ann_w_ih), 0},
-      {cfg->ann_w_ho, sizeof(cfg->ann_w_ho), 0},
+      {cfg.ann_w_ih, sizeof(cfg.ann_w_ih), 0},
+      {cfg.ann_w_ho, sizeof(cfg.ann_w_ho), 0},
       {band_tab.data(), band_tab.size() * sizeof(int), 0},
       {band_c2.data(), band_c2.size() * sizeof(int), 0},
   };
@@ -245,17 +233,17 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   }
   std::vector<char> host(total, 0);
   for (auto &p : pieces) std::memcpy(host.data() + p.off, p.src, p.bytes);
-  hipError_t e = hipMalloc(&h->d_tables, total);
+  void *slab = nullptr;
+  hipError_t e = hipMalloc(&slab, total);
+  if (e != hipSuccess) return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(tables): ") + hipGetErrorString(e));
+  e = hipMemcpy(slab, host.data(), total, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    delete h;
-    return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(tables): ") + hipGetErrorString(e));
-  }
-  e = hipMemcpy(h->d_tables, host.data(), total, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(h->d_tables);
-    delete h;
+    (void)hipFree(slab);
     return crn::fail(CRN_ERR_DEVICE, std::string("hipMemcpy(tables): ") + hipGetErrorString(e));
   }
+  // hipFree waits for the device: launches still reading the previous slab (crn_sense_set_bands on a live handle) finish first
+  if (h->d_tables) (void)hipFree(h->d_tables);
+  h->d_tables = slab;
   char *base = static_cast<char *>(h->d_tables);
   h->d_tw1 = reinterpret_cast<const float2 *>(base + pieces[0].off);
   h->d_tw2 = reinterpret_cast<const float2 *>(base + pieces[1].off);
@@ -270,6 +258,44 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   h->d_who = reinterpret_cast<const double *>(base + pieces[10].off);
   h->d_band_tab = reinterpret_cast<const int *>(base + pieces[11].off);
   h->d_band_c2 = reinterpret_cast<const int *>(base + pieces[12].off);
+  return CRN_OK;
+}
+
+extern "C" {
+
+const char *crn_last_error(void) { return crn::g_err.c_str(); }
+int crn_abi_version(void) { return CRN_ABI_VERSION; }
+
+int crn_build_info(int32_t *built_hip, int32_t *runtime_hip) {
+  const int built = HIP_VERSION;   // hip/hip_version.h of the toolchain that compiled this file
+  int rt = 0;
+  if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = 0;
+  if (built_hip) *built_hip = built;
+  if (runtime_hip) *runtime_hip = rt;
+  if (rt == 0) return crn::fail(CRN_ERR_STATE, "crn_build_info: no HIP runtime answers");
+  if (rt / 10000000 != built / 10000000 || rt < 70000000)
+    return crn::fail(CRN_ERR_STATE, "libcrnsense was built with HIP " + std::to_string(built) + " and needs a HIP runtime of the same major "
+                                    "version, ROCm 7.0 or newer (gfx950); this machine's reports " + std::to_string(rt));
+  return CRN_OK;
+}
+
+int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
+  if (!out) return crn::fail(CRN_ERR_ARG, "crn_sense_create: null out");
+  *out = nullptr;
+  if (int rc = validate(cfg)) return rc;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return crn::fail(CRN_ERR_DEVICE, "no HIP device visible (libcrnsense has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return crn::fail(CRN_ERR_ARG, "cfg.device out of range");
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  crn_handle *h = new (std::nothrow) crn_handle();
+  if (!h) return crn::fail(CRN_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  if (int rc = build_tables(h)) {
+    delete h;
+    return rc;
+  }
   *out = h;
   return CRN_OK;
 }
@@ -655,6 +681,74 @@ int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands
   HIP_TRY(hipMemcpyAsync(const_cast<float *>(h->d_thresh), h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 416, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
   return CRN_OK;
+}
+
+int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[6][4], double threshold, void *stream) {
+  if (!h || !w_ih || !w_ho) return crn::fail(CRN_ERR_ARG, "null handle / weights");
+  if (h->cfg.decide != CRN_DECIDE_ANN) return crn::fail(CRN_ERR_STATE, "crn_sense_set_ann: the handle does not decide with the network");
+  if (!(threshold > 0.0 && threshold < 1.0)) return crn::fail(CRN_ERR_ARG, "threshold must be in (0, 1)");
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 6; j++)
+      if (!std::isfinite(w_ih[i][j])) return crn::fail(CRN_ERR_ARG, "non-finite weight");
+  for (int j = 0; j < 6; j++)
+    for (int k = 0; k < 4; k++)
+      if (!std::isfinite(w_ho[j][k])) return crn::fail(CRN_ERR_ARG, "non-finite weight");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::memcpy(h->cfg.ann_w_ih, w_ih, sizeof(h->cfg.ann_w_ih));
+  std::memcpy(h->cfg.ann_w_ho, w_ho, sizeof(h->cfg.ann_w_ho));
+  h->cfg.ann_threshold = threshold;   // rides in the launch parameters
+  // the device copies the kernels read: the two tables and the packed band table's weight words (layout: crn_kernels.h)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_wih), h->cfg.ann_w_ih, sizeof(h->cfg.ann_w_ih), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_who), h->cfg.ann_w_ho, sizeof(h->cfg.ann_w_ho), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 544, h->cfg.ann_w_ih, sizeof(h->cfg.ann_w_ih), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 604, h->cfg.ann_w_ho, sizeof(h->cfg.ann_w_ho), hipMemcpyHostToDevice, st));
+  return CRN_OK;
+}
+
+int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs, int32_t n_bands, const float *thresh) {
+  if (!h || !segs) return crn::fail(CRN_ERR_ARG, "null handle / segments");
+  if (n_segs < 1 || n_segs > CRN_MAX_SEGS) return crn::fail(CRN_ERR_ARG, "n_segs out of range");
+  crn_cfg next = h->cfg;
+  next.n_segs = n_segs;
+  next.n_bands = n_bands;
+  std::memcpy(next.segs, segs, sizeof(crn_band_seg) * (size_t)n_segs);
+  if (thresh) {
+    if (n_bands >= 1 && n_bands <= CRN_MAX_BANDS) std::memcpy(next.thresh, thresh, sizeof(float) * (size_t)n_bands);
+  } else if (n_bands != h->cfg.n_bands) {
+    return crn::fail(CRN_ERR_ARG, "crn_sense_set_bands: a different number of bands needs its thresholds");
+  }
+  if (int rc = validate(&next)) return rc;   // same rules as crn_sense_create (DECIDE_ANN keeps its 4 bands, ref_band stays inside)
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const crn_cfg prev = h->cfg;
+  h->cfg = next;
+  if (int rc = build_tables(h)) {            // a fresh slab; the old one is freed once the device is idle
+    h->cfg = prev;
+    return rc;
+  }
+  return CRN_OK;
+}
+
+int crn_sense_synchronize(crn_handle *h, void *stream) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return CRN_OK;
+}
+
+int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs, float *nf_out) {
+  if (!h || !features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
+  if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int64_t n = std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
+  const size_t bytes = (size_t)n * h->cfg.n_bands * sizeof(float);
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+  hipError_t e = hipMemcpy(d, features, bytes, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? crn_noise_floor_device(h, d, n, nf_out, nullptr)
+                           : crn::fail(CRN_ERR_DEVICE, std::string("hipMemcpy(features): ") + hipGetErrorString(e));
+  (void)hipFree(d);
+  return rc;
 }
 
 int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,

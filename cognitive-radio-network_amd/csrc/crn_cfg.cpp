@@ -4,8 +4,11 @@
 // CE_Predictive_Node.cpp:78-120,173-191,245-261).  crn_cfg_reference() restates them as data so
 // the same kernel serves the reference-exact mode and the BASELINE.json generalisations.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <string>
 
 #include "../../include/crn_sense.h"
 #include "crn_internal.h"
@@ -70,6 +73,68 @@ int crn_cfg_reference(crn_cfg *cfg) {
   return CRN_OK;
 }
 
+int crn_cfg_reference_scaled(crn_cfg *cfg, int32_t fft_len) {
+  if (int rc = crn_cfg_reference(cfg)) return rc;
+  if (fft_len < 512 || fft_len % 512 != 0) return crn::fail(CRN_ERR_ARG, "fft_len must be a multiple of 512");
+  const int s = fft_len / 512;
+  cfg->fft_len = fft_len;
+  cfg->hop = fft_len;
+  for (int i = 0; i < 5; i++) cfg->segs[i] = crn_band_seg{kRefSegs[i].lo * s, kRefSegs[i].hi * s, kRefSegs[i].band};
+  return CRN_OK;
+}
+
+// Weights file: plain text, '#' starts a comment, then 30 + 24 numbers in the reference's array order —
+// WeightIH[i][j], i = 0..4, j = 0..5 (row-major, column 0 unused) and WeightHO[j][k], j = 0..5, k = 0..3 (column 0 unused) —
+// optionally followed by the decision threshold.  %.17g round-trips a double exactly.
+int crn_cfg_save_ann(const crn_cfg *cfg, const char *path) {
+  if (!cfg || !path) return crn::fail(CRN_ERR_ARG, "crn_cfg_save_ann: null argument");
+  FILE *f = std::fopen(path, "w");
+  if (!f) return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_save_ann: cannot write ") + path);
+  std::fprintf(f, "# libcrnsense 4-5-3 network: WeightIH[5][6] then WeightHO[6][4] (reference indexing, CE_Predictive_Node.hpp:66,71), then the threshold\n");
+  for (int i = 0; i <= CRN_ANN_IN; i++) {
+    for (int j = 0; j <= CRN_ANN_HID; j++) std::fprintf(f, "%.17g ", cfg->ann_w_ih[i][j]);
+    std::fprintf(f, "\n");
+  }
+  for (int j = 0; j <= CRN_ANN_HID; j++) {
+    for (int k = 0; k <= CRN_ANN_OUT; k++) std::fprintf(f, "%.17g ", cfg->ann_w_ho[j][k]);
+    std::fprintf(f, "\n");
+  }
+  std::fprintf(f, "%.17g\n", cfg->ann_threshold);
+  const bool ok = std::ferror(f) == 0;
+  if (std::fclose(f) != 0 || !ok) return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_save_ann: write error on ") + path);
+  return CRN_OK;
+}
+
+int crn_cfg_load_ann(crn_cfg *cfg, const char *path) {
+  if (!cfg || !path) return crn::fail(CRN_ERR_ARG, "crn_cfg_load_ann: null argument");
+  FILE *f = std::fopen(path, "r");
+  if (!f) return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_load_ann: cannot read ") + path);
+  double v[55];
+  int n = 0;
+  char tok[128];
+  while (n < 55 && std::fscanf(f, "%127s", tok) == 1) {
+    if (tok[0] == '#') {  // comment: skip the rest of the line
+      int ch;
+      while ((ch = std::fgetc(f)) != EOF && ch != '\n') {}
+      continue;
+    }
+    char *end = nullptr;
+    const double x = std::strtod(tok, &end);
+    if (end == tok || *end != '\0' || !std::isfinite(x)) {
+      std::fclose(f);
+      return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_load_ann: not a finite number: '") + tok + "' in " + path);
+    }
+    v[n++] = x;
+  }
+  std::fclose(f);
+  if (n != 54 && n != 55)
+    return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_load_ann: expected 54 weights (+ threshold), found ") + std::to_string(n) + " numbers in " + path);
+  std::memcpy(cfg->ann_w_ih, v, sizeof(cfg->ann_w_ih));
+  std::memcpy(cfg->ann_w_ho, v + 30, sizeof(cfg->ann_w_ho));
+  if (n == 55) cfg->ann_threshold = v[54];
+  return CRN_OK;
+}
+
 int crn_cfg_energy_scaled(crn_cfg *cfg, int32_t fft_len, float lambda) {
   if (!cfg) return crn::fail(CRN_ERR_ARG, "crn_cfg_energy_scaled: null cfg");
   if (fft_len < 512 || fft_len % 512 != 0) return crn::fail(CRN_ERR_ARG, "fft_len must be a multiple of 512");
@@ -114,6 +179,15 @@ int crn_cfg_welch(crn_cfg *cfg, int32_t fft_len, int32_t frames_per_epoch, int32
     cfg->thresh[b] = std::numeric_limits<float>::infinity();
   }
   cfg->ref_band = -1;
+  return CRN_OK;
+}
+
+int crn_cfg_welch_scaled(crn_cfg *cfg, int32_t fft_len, int32_t frames_per_epoch, float lambda) {
+  if (int rc = crn_cfg_energy_scaled(cfg, fft_len, lambda)) return rc;
+  if (frames_per_epoch < 1) return crn::fail(CRN_ERR_ARG, "crn_cfg_welch_scaled: frames_per_epoch < 1");
+  cfg->frames_per_epoch = frames_per_epoch;
+  cfg->hop = fft_len / 2;
+  cfg->window = CRN_WINDOW_HANN;
   return CRN_OK;
 }
 

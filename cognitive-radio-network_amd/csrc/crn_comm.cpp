@@ -160,6 +160,21 @@ int crn_comm_local(crn_comm *c, int64_t step, void *stream, uint8_t **d_local) {
   return CRN_OK;
 }
 
+int crn_comm_local_addr(crn_comm *c, int64_t step, uint8_t **d_local) {
+  if (!c || !d_local || step < 0) return crn::fail(CRN_ERR_ARG, "crn_comm_local_addr: bad argument");
+  *d_local = c->d_local + (size_t)(step % c->depth) * c->bytes;
+  return CRN_OK;
+}
+
+int crn_comm_wait(crn_comm *c, int64_t step, void *stream) {
+  if (!c || step < 0) return crn::fail(CRN_ERR_ARG, "crn_comm_wait: bad argument");
+  const int s = (int)(step % c->depth);
+  if (!c->pending[s]) return CRN_OK;     // no gather queued on this slot since it was last handed out
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->done[s], 0));
+  return CRN_OK;                          // the slot stays pending: crn_comm_local / crn_comm_finish still order their stream behind it
+}
+
 int crn_comm_allgather(crn_comm *c, int64_t step, void *stream) {
   if (!c || step < 0) return crn::fail(CRN_ERR_ARG, "crn_comm_allgather: bad argument");
   const int s = (int)(step % c->depth);

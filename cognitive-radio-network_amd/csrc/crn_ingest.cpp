@@ -8,6 +8,11 @@
 // (H2D -> sensing kernel -> D2H on a private stream, completion by event) and files the results;
 // filling continues in the other buffer.
 //
+// Disjoint frames (hop == fft_len: the reference's own shape): a packet is a frame, an epoch is K packets, the kernel zero-pads
+// each to N.  Overlapped frames (hop < fft_len: the Welch plans): the packets of an epoch are laid end to end as one contiguous
+// run of samples — P = ceil(((K - 1) hop + N) / L) of them — and the kernel cuts its K overlapped N-sample frames out of that run
+// (epoch stride P L).
+//
 // Threads: the caller's thread (the CE thread: crn_ingest_push / _poll run inside execute(), with
 // CE_mutex held) touches pinned memory, a few counters, and a mutex for the hand-off queues — never
 // the HIP runtime, never the allocator on the packet path.  When the buffer it would have to fill is
@@ -42,7 +47,7 @@ namespace {
 struct Slot {
   int32_t stream;  // -1: a hole (its epoch moved on to the next batch; nothing to report)
   int64_t seq;
-  int npk;         // packets staged
+  int npk;         // packets staged (of P)
 };
 
 enum : int { kFree = 0, kQueued = 1 };  // Batch::state: owned by the caller / by the launcher thread
@@ -57,7 +62,7 @@ struct Batch {
   int assigned = 0;             // slots handed to streams, in order of epoch start
   int complete = 0;             // of which hold all K packets
   int launched = 0;             // slots of the launch handed to the launcher thread
-  int L = 0;                    // packet length of that launch
+  int L = 0, P = 0;             // packet length and packets per epoch of that launch
   std::chrono::steady_clock::time_point t_handoff;   // when the pushing thread handed it over (written before state = kQueued)
   std::atomic<int> state{kFree};
 };
@@ -68,8 +73,11 @@ struct crn_ingest {
   crn_handle *h = nullptr;
   crn_cfg cfg;
   int n_streams = 0, L = 0, cap = 0, B = 0, C = 0, K = 0;
+  int P = 0;                               // packets per epoch: K (disjoint frames) or ceil(((K - 1) hop + N) / L) (overlapped)
+  bool overlapped = false;                 // cfg.hop < cfg.fft_len
   size_t sample_bytes = 8;                 // 8: complex floats; 4: the radio's wire format (crn_ingest_create_sc16)
-  size_t epoch_bytes = 0;                  // K * L * sample_bytes (dense: the kernel is run with samples_per_frame = L)
+  size_t epoch_bytes = 0;                  // P * L * sample_bytes: slot pitch for the current packet length
+  size_t epoch_cap_bytes = 0;              // largest epoch_bytes any packet length <= cap can need (buffers are sized for it)
   size_t off_ann = 0, off_dec = 0, off_occ = 0, res_bytes = 0;
   hipStream_t stream = nullptr;
   Batch batch[2];
@@ -103,11 +111,18 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// packets of L samples that make up one epoch
+int packets_per_epoch(const crn_cfg &c, int L) {
+  if (c.hop == c.fft_len) return c.frames_per_epoch;
+  const long long span = (long long)(c.frames_per_epoch - 1) * c.hop + c.fft_len;
+  return (int)((span + L - 1) / L);
+}
+
 // ---- launcher thread -------------------------------------------------------------------------
 
 // H2D + kernel + D2H + event for one batch; returns an error message or "".
 std::string enqueue(crn_ingest *g, Batch &b) {
-  const size_t in_bytes = (size_t)b.launched * (size_t)g->K * b.L * g->sample_bytes;
+  const size_t in_bytes = (size_t)b.launched * (size_t)b.P * b.L * g->sample_bytes;
   // a small batch (the engine's one epoch): the kernel reads the pinned slots and writes the pinned results over the bus itself —
   // one launch instead of upload + launch + download: the kernel takes 30 instead of 23 us for one reference epoch, the results
   // are readable 15-19 us sooner (tools/ring_rate: 89 -> 74 us; 8 epochs: 92 -> 73 us).  $CRN_INGEST_ZEROCOPY_BYTES: largest
@@ -124,9 +139,12 @@ std::string enqueue(crn_ingest *g, Batch &b) {
   out.occupancy = reinterpret_cast<uint8_t *>(res + g->off_occ);
   out.spectrum = nullptr;
   const void *src = zero_copy ? b.h_iq : b.d_iq;
+  // disjoint frames: K packets zero-padded to N each, dense epochs; overlapped: whole frames cut from the epoch's run of P L samples
+  const int32_t spf = g->overlapped ? g->cfg.fft_len : b.L;
+  const int64_t stride = g->overlapped ? (int64_t)b.P * b.L : 0;
   const int rc = g->sample_bytes == 4
-                     ? crn_sense_run_device_sc16(g->h, static_cast<const int16_t *>(src), b.launched, b.L, 0, &out, g->stream)
-                     : crn_sense_run_device(g->h, static_cast<const float *>(src), b.launched, b.L, 0, &out, g->stream);
+                     ? crn_sense_run_device_sc16(g->h, static_cast<const int16_t *>(src), b.launched, spf, stride, &out, g->stream)
+                     : crn_sense_run_device(g->h, static_cast<const float *>(src), b.launched, spf, stride, &out, g->stream);
   if (rc != CRN_OK) return crn_last_error();
   if (!zero_copy) e = hipMemcpyAsync(b.h_res, b.d_res, g->res_bytes, hipMemcpyDeviceToHost, g->stream);
   if (e == hipSuccess) e = hipEventRecord(b.done, g->stream);
@@ -198,7 +216,7 @@ void launcher_main(crn_ingest *g) {
     // microseconds late: keep looking for up to 150 us after the hand-off unless new work is waiting to be launched (hand-off to
     // decision 106 -> 58 us).  Big batches take as long to fill as to run and polling through them costs the pushing thread
     // 10-30 % of its rate (measured, tools/ring_rate): they sleep.
-    const bool small = (size_t)b.launched * (size_t)g->K * (size_t)b.L * 8 <= (size_t)512 * 1024;
+    const bool small = (size_t)b.launched * (size_t)b.P * (size_t)b.L * g->sample_bytes <= g->zero_copy_bytes;
     const auto spin = std::chrono::microseconds(small ? g->spin_us : 0);
     hipError_t q = hipEventQuery(b.done);
     while (q == hipErrorNotReady && !g->work_waiting.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - b.t_handoff < spin)
@@ -229,7 +247,9 @@ void launcher_main(crn_ingest *g) {
     }
     // new work wakes it early.  (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer models;
     // wait_for would be pthread_cond_clockwait, which gcc 11's libtsan does not intercept: tests/harness/ring_unit.cpp)
-    if (g->work.empty()) g->cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(20));
+    // A small batch is back within tens of microseconds: look again soon.  A big one takes as long to run as to fill: sleep
+    // through most of it (200 us steps instead of 50 000 wake-ups a second).
+    if (g->work.empty()) g->cv_work.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(small ? 20 : 200));
   }
 }
 
@@ -257,12 +277,13 @@ int launch(crn_ingest *g) {
   const int n = b.assigned;
   b.launched = n;
   b.L = g->L;
+  b.P = g->P;
   if (holes) {
     // open epochs continue in the other buffer (their packets so far are copied over: this only
     // happens when streams run at different rates or on an explicit flush)
     for (int i = 0; i < n; i++) {
       Slot &sl = b.slots[i];
-      if (sl.stream < 0 || sl.npk == g->K) continue;
+      if (sl.stream < 0 || sl.npk == g->P) continue;
       const int j = o.assigned++;
       o.slots[j] = sl;
       std::memcpy(o.h_iq + (size_t)j * g->epoch_bytes, b.h_iq + (size_t)i * g->epoch_bytes, (size_t)sl.npk * g->L * g->sample_bytes);
@@ -304,7 +325,6 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   crn_cfg cfg;
   if (int rc = crn_sense_cfg_of(h, &cfg)) return rc;
   if (n_streams < 1 || epochs_per_batch < 1) return crn::fail(CRN_ERR_ARG, "n_streams / epochs_per_batch < 1");
-  if (cfg.hop != cfg.fft_len) return crn::fail(CRN_ERR_ARG, "the ingest ring takes disjoint frames (hop == fft_len)");
   if (samples_per_packet < 1 || samples_per_packet > cfg.fft_len)
     return crn::fail(CRN_ERR_ARG, "samples_per_packet must be in 1..fft_len");
   HIP_TRY(hipSetDevice(cfg.device));
@@ -318,8 +338,12 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   // every stream can have one epoch open: with C >= n_streams a full buffer always holds a complete one
   g->C = epochs_per_batch > n_streams ? epochs_per_batch : n_streams;
   g->K = cfg.frames_per_epoch;
+  g->overlapped = cfg.hop != cfg.fft_len;
+  g->P = packets_per_epoch(cfg, g->L);
   g->sample_bytes = sample_bytes;
-  g->epoch_bytes = (size_t)g->K * g->L * sample_bytes;
+  g->epoch_bytes = (size_t)g->P * g->L * sample_bytes;
+  // overlapped: P(L) L < span + L for every L <= cap
+  g->epoch_cap_bytes = g->overlapped ? ((size_t)(g->K - 1) * cfg.hop + cfg.fft_len + g->cap) * sample_bytes : g->epoch_bytes;
   const size_t nb = (size_t)cfg.n_bands;
   g->off_ann = align_up((size_t)g->C * nb * sizeof(float), 256);
   g->off_dec = g->off_ann + align_up((size_t)g->C * 3 * sizeof(double), 256);
@@ -331,7 +355,7 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     Batch &b = g->batch[i];
     b.slots.resize(g->C);
-    const size_t iq_bytes = (size_t)g->C * g->epoch_bytes;
+    const size_t iq_bytes = (size_t)g->C * g->epoch_cap_bytes;
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_iq), iq_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.d_iq), iq_bytes);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_res), g->res_bytes, hipHostMallocDefault);
@@ -358,7 +382,8 @@ int crn_ingest_set_packet_len(crn_ingest *g, int32_t samples_per_packet) {
   if (!is_free(b)) return crn::fail(CRN_ERR_BUSY, "ingest ring: both batch buffers are in flight");
   if (b.assigned != 0) return crn::fail(CRN_ERR_STATE, "crn_ingest_set_packet_len: epochs are staged (flush first)");
   g->L = samples_per_packet;
-  g->epoch_bytes = (size_t)g->K * g->L * g->sample_bytes;
+  g->P = packets_per_epoch(g->cfg, g->L);
+  g->epoch_bytes = (size_t)g->P * g->L * g->sample_bytes;
   return CRN_OK;
 }
 
@@ -391,7 +416,7 @@ static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, siz
     Slot &s = b.slots[sl];
     std::memcpy(b.h_iq + (size_t)sl * g->epoch_bytes + (size_t)s.npk * g->L * g->sample_bytes, iq_packet, (size_t)g->L * g->sample_bytes);
     g->packets++;
-    if (++s.npk < g->K) return CRN_OK;
+    if (++s.npk < g->P) return CRN_OK;
     g->open_slot[stream] = -1;
     b.complete++;
     if (launch_due(g, b)) {
@@ -424,8 +449,18 @@ int crn_ingest_flush(crn_ingest *g) {
 
 int crn_ingest_wait(crn_ingest *g) {
   if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
-  wait_free(g, g->batch[g->fill]);
+  Batch &b = g->batch[g->fill];
+  wait_free(g, b);
+  // a push can also be refused because the hand-off of THIS buffer needs the other one (open epochs move over): then that is
+  // the buffer to wait for, not the one being filled
+  if (b.assigned == g->C && b.complete != b.assigned) wait_free(g, g->batch[g->fill ^ 1]);
   return sticky_error(g);
+}
+
+int crn_ingest_packets_per_epoch(crn_ingest *g, int32_t *n_packets) {
+  if (!g || !n_packets) return crn::fail(CRN_ERR_ARG, "null argument");
+  *n_packets = g->P;
+  return CRN_OK;
 }
 
 int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, int32_t *n_out) {

@@ -174,7 +174,7 @@ class DeviceOccupancyExchange:
 
     def local_host(self, i):
         import numpy as np
-        raw = self.cs.device_to_host(self.comm.local(i, 0), self.epochs * self.n_bands)
+        raw = self.cs.device_to_host(self.comm.local_addr(i), self.epochs * self.n_bands)   # an accessor: no stream waits, slot state untouched
         return np.frombuffer(raw, dtype=np.uint8).reshape(self.epochs, self.n_bands)
 
     def close(self):

@@ -45,6 +45,9 @@ static void timed_execute(ExtensibleCognitiveRadio &ecr) {
 
 static void print_new_epochs(ExtensibleCognitiveRadio &ecr, CE_Predictive_Node_GPU *engine, long *seen) {
   if (engine->epochs_closed == *seen) return;
+  // epochs that closed before the newest one inside the same execute() (-b > 1): their decisions only
+  for (long e = *seen; e + 1 < engine->epochs_closed; e++)
+    if (engine->epochs_closed - e <= 64) printf("epoch %ld decision %d\n", e, engine->recent_decisions[e % 64]);
   *seen = engine->epochs_closed;
   double tx = 0.0;
   for (size_t i = ecr.calls.size(); i-- > 0;) {
@@ -93,10 +96,13 @@ int main(int argc, char **argv) {
 
   long seen = 0;
   long packets = 0;
+  // packets per decision: 10 in the reference (fft_averaging, CE_Predictive_Node.hpp:32); -k and the Welch modes change it
+#define PPE (engine->packets_per_epoch())
+#define EPOCHS_DONE (engine->epochs_closed + engine->epochs_calibrating)
   if (realtime) {
     bool more = true;
     const double t_end = ecr.now() + 30.0;
-    while ((more || engine->epochs_closed * 10 < packets) && ecr.now() < t_end) {
+    while ((more || EPOCHS_DONE * PPE < packets) && ecr.now() < t_end) {
       if (more && ecr.ce_sensing_flag) {  // :1310: forward a packet only while sensing is on
         more = fread(buf.data(), sizeof(std::complex<float>), (size_t)L, f) == (size_t)L;
         if (!more) continue;
@@ -108,7 +114,7 @@ int main(int argc, char **argv) {
       const bool rx = ecr.CE_metrics.CE_event == ExtensibleCognitiveRadio::USRP_RX_SAMPS;
       timed_execute(ecr);
       packets -= engine->packets_dropped;  // a refused packet is not part of any epoch
-      if (rx && !engine->packets_dropped && packets % 10 == 0) g_launch_us.push_back(g_exec_us.back());
+      if (rx && !engine->packets_dropped && packets % PPE == 0) g_launch_us.push_back(g_exec_us.back());
       engine->packets_dropped = 0;
       print_new_epochs(ecr, engine, &seen);
     }
@@ -124,10 +130,11 @@ int main(int argc, char **argv) {
         timed_execute(ecr);
       } while (engine->packets_dropped);
       packets++;
-      if (packets % 10 == 0) g_launch_us.push_back(g_exec_us.back());
+      if (packets % PPE == 0) g_launch_us.push_back(g_exec_us.back());
       // the decision of an epoch lands on a later event: keep the CE worker's TIMEOUT events coming
       // (ce_timeout_ms = 0 in scenarios/predictive_model.cfg:61) at epoch ends
-      for (int spin = 0; packets % 10 == 0 && engine->epochs_closed < packets / 10 && spin < 2000000; spin++) {
+      // (with -b B a launch carries B epochs: their decisions land together after the B-th)
+      for (int spin = 0; packets % (PPE * engine->epochs_per_launch()) == 0 && EPOCHS_DONE < packets / PPE && spin < 2000000; spin++) {
         ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::TIMEOUT;
         timed_execute(ecr);
       }
@@ -135,6 +142,8 @@ int main(int argc, char **argv) {
     }
   }
   fclose(f);
+  engine->flush();   // epochs of an incomplete last batch (-b > 1)
+  print_new_epochs(ecr, engine, &seen);
   printf("calls");
   for (size_t i = 0; i < ecr.calls.size() && i < 12; i++) printf(" %s(%g)", ecr.calls[i].name.c_str(), ecr.calls[i].arg);
   printf("\n");

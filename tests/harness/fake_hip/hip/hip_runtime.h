@@ -23,24 +23,40 @@ typedef fake_hip_event *hipEvent_t;
 
 extern std::atomic<long long> g_fake_gpu_latency_ns;   // defined by the test: how long a "batch" stays on the "GPU"
 
+// A test marks its own thread (fake_hip_watch_thread = true) around the calls it wants to prove HIP-free — the engine's execute()
+// runs with CE_mutex held and must only enqueue: every stand-in below counts a call made from a marked thread, and the two that
+// can block count separately.  (thread_local inline variables: one instance per thread across translation units, C++17.)
+inline thread_local bool fake_hip_watch_thread = false;
+inline std::atomic<long long> fake_hip_calls_on_watched_threads{0}, fake_hip_waits_on_watched_threads{0};
+inline void fake_hip_note(bool blocking = false) {
+  if (fake_hip_watch_thread) {
+    fake_hip_calls_on_watched_threads++;
+    if (blocking) fake_hip_waits_on_watched_threads++;
+  }
+}
+
 inline long long fake_hip_now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorNotReady ? "not ready" : "fake hip error"; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
-inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
-inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new fake_hip_stream(); return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new fake_hip_event(); (*e)->ready_at_ns.store(0); return hipSuccess; }
-inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->ready_at_ns.store(fake_hip_now_ns() + g_fake_gpu_latency_ns.load()); return hipSuccess; }
-inline hipError_t hipEventQuery(hipEvent_t e) { return fake_hip_now_ns() >= e->ready_at_ns.load() ? hipSuccess : hipErrorNotReady; }
+inline hipError_t hipSetDevice(int) { fake_hip_note(); return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { fake_hip_note(); *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { fake_hip_note(); return hipMalloc(p, n); }
+inline hipError_t hipFree(void *p) { fake_hip_note(); std::free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void *p) { fake_hip_note(); std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { fake_hip_note(); std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { fake_hip_note(); *s = new fake_hip_stream(); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { fake_hip_note(); delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { fake_hip_note(true); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { fake_hip_note(); *e = new fake_hip_event(); (*e)->ready_at_ns.store(0); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { fake_hip_note(); delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { fake_hip_note(); e->ready_at_ns.store(fake_hip_now_ns() + g_fake_gpu_latency_ns.load()); return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t e) { fake_hip_note(); return fake_hip_now_ns() >= e->ready_at_ns.load() ? hipSuccess : hipErrorNotReady; }
 inline hipError_t hipEventSynchronize(hipEvent_t e) {
+  fake_hip_note(true);
+  const bool w = fake_hip_watch_thread;
+  fake_hip_watch_thread = false;   // (the polling below is this wait, not further calls)
+  struct Restore { bool w; ~Restore() { fake_hip_watch_thread = w; } } restore{w};
   while (hipEventQuery(e) != hipSuccess) std::this_thread::sleep_for(std::chrono::microseconds(20));
   return hipSuccess;
 }

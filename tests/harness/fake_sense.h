@@ -1,7 +1,10 @@
 // fake_sense.h — TEST INFRASTRUCTURE: what csrc/crn_ingest.cpp (and the engine) link against in libcrnsense, restated for
 // CPU-only unit tests (ring_unit.cpp, engine_unit.cpp) together with tests/harness/fake_hip.  The sensing stand-in:
 //   features[0] of an epoch = sum of all its samples, features[1] = its first sample, decision = L (ring_unit) or
-//   the rounded first sample (engine_unit: g_fake_decision_from_data), ann_out = {0, 1, 2}.
+//   the rounded first sample (engine_unit: g_fake_decision_from_data), ann_out = {0, 1, 2}; with threshold plans the "decision"
+//   d also marks occupancy[d] (4-band plans) or every band of channel d's first reference bin (64-band plans), so that the
+//   engine's channel mapping can be watched.  Overlapped frames (hop < fft_len): an epoch is the contiguous run of
+//   (K - 1) hop + N samples starting `epoch_stride` samples after the previous one, L must be fft_len.
 #ifndef CRN_FAKE_SENSE_H
 #define CRN_FAKE_SENSE_H
 #include <string.h>
@@ -26,22 +29,42 @@ extern "C" {
 const char *crn_last_error(void) { return crn::g_err.c_str(); }
 struct crn_handle { crn_cfg cfg; };
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
-int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t L, int64_t, const crn_out *o, void *) {
+static std::atomic<long long> g_fake_launches{0};
+static std::atomic<int> g_fake_last_L{0};
+static std::atomic<long long> g_fake_last_stride{0};
+int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int32_t L, int64_t stride, const crn_out *o, void *) {
   if (g_fail_next_launch.exchange(0)) return crn::fail(CRN_ERR_DEVICE, "forced launch failure");
   const int K = h->cfg.frames_per_epoch, nb = h->cfg.n_bands;
+  const bool overlapped = h->cfg.hop != h->cfg.fft_len;
+  if (overlapped && L != h->cfg.fft_len) return crn::fail(CRN_ERR_ARG, "overlapped frames need samples_per_frame == fft_len");
+  const long long span = overlapped ? (long long)(K - 1) * h->cfg.hop + h->cfg.fft_len : (long long)K * L;
+  if (stride <= 0) stride = overlapped ? (long long)K * h->cfg.hop : (long long)K * L;
+  g_fake_launches++;
+  g_fake_last_L = L;
+  g_fake_last_stride = stride;
   for (int64_t e = 0; e < n_epochs; e++) {
-    const float *x = d_iq + (size_t)e * K * L * 2;
+    const float *x = d_iq + (size_t)e * stride * 2;
     double s = 0;
-    for (int i = 0; i < K * L * 2; i++) s += x[i];
+    for (long long i = 0; i < span * 2; i++) s += x[i];
     if (o->features) {   // any output may be NULL (crn_out)
       for (int b = 0; b < nb; b++) o->features[e * nb + b] = 0.f;
       o->features[e * nb + 0] = (float)s;
       o->features[e * nb + 1] = x[0];
     }
-    if (o->decision) o->decision[e] = g_fake_decision_from_data.load() ? (int)(x[0] + 0.5f) : L;
+    const int d = g_fake_decision_from_data.load() ? (int)(x[0] + 0.5f) : L;
+    if (o->decision) o->decision[e] = d;
     if (o->ann_out)
       for (int k = 0; k < 3; k++) o->ann_out[e * 3 + k] = (double)k;
-    if (o->occupancy) memset(o->occupancy + e * nb, 0, (size_t)nb);
+    if (o->occupancy) {
+      memset(o->occupancy + e * nb, 0, (size_t)nb);
+      if (g_fake_decision_from_data.load() && h->cfg.decide == CRN_DECIDE_THRESHOLD && d >= 1 && d <= 3) {
+        // 4-band plans {NF, CH1, CH2, CH3}: band d; equal-band plans: the band holding the first bin of the reference's channel d
+        // (CE_Predictive_Node.cpp:173-191: CH1 from bin 0, CH2 from 55, CH3 from 189 of 512)
+        const int first_bin[4] = {0, 0, 55, 189};
+        const int b = nb == 4 ? d : first_bin[d] * (h->cfg.fft_len / 512) / (h->cfg.fft_len / nb);
+        o->occupancy[e * nb + b] = 1;
+      }
+    }
   }
   return CRN_OK;
 }

@@ -301,6 +301,83 @@ int main() {
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
   }
   g_fake_gpu_latency_ns = 0;
+
+  // 9. overlapped frames (a Welch plan: hop = N/2): an epoch is ONE contiguous run of P = ceil(((K - 1) hop + N) / L) packets, the
+  // launch asks for whole frames (samples_per_frame = N) with the epoch stride P L; a change of packet length changes P; three
+  // streams interleaved; the stand-in's checksum covers exactly the (K - 1) hop + N samples the kernel would read
+  {
+    crn_handle hw = h;
+    hw.cfg.fft_len = 1024;
+    hw.cfg.hop = 512;
+    hw.cfg.frames_per_epoch = 8;
+    hw.cfg.decide = CRN_DECIDE_THRESHOLD;
+    const long span = 7 * 512 + 1024;
+    for (int L : {364, 512, 1000}) {
+      const int S = 3, P = (int)((span + L - 1) / L);
+      REQUIRE(crn_ingest_create(&hw, S, 1024, 2, &g) == CRN_OK);
+      REQUIRE(crn_ingest_set_packet_len(g, L) == CRN_OK);
+      int32_t pp = 0;
+      REQUIRE(crn_ingest_packets_per_epoch(g, &pp) == CRN_OK && pp == P);
+      std::vector<crn_epoch_result> all;
+      std::vector<double> want((size_t)S * 4, 0.0);
+      for (long e = 0; e < 4; e++)
+        for (int p = 0; p < P; p++)
+          for (int st = 0; st < S; st++) {
+            std::vector<float> pk((size_t)L * 2);
+            for (int i = 0; i < L; i++) {
+              pk[2 * i] = (float)((st * 31 + e * 7 + p * 3 + i) % 97);
+              pk[2 * i + 1] = 0.5f;
+              if ((long)p * L + i < span) want[(size_t)st * 4 + e] += (double)pk[2 * i] + 0.5;   // the tail of the last packet is beyond the last frame
+            }
+            int rc;
+            while ((rc = crn_ingest_push(g, st, pk.data())) == CRN_ERR_BUSY) REQUIRE(crn_ingest_wait(g) == CRN_OK);
+            REQUIRE(rc == CRN_OK);
+            collect(g, &all);
+          }
+      REQUIRE(crn_ingest_drain(g) == CRN_OK);
+      collect(g, &all);
+      REQUIRE(all.size() == (size_t)S * 4);
+      REQUIRE(g_fake_last_L.load() == 1024 && g_fake_last_stride.load() == (long long)P * L);
+      for (const crn_epoch_result &r : all) REQUIRE(r.features[0] == (float)want[(size_t)r.stream * 4 + r.epoch_seq]);
+      REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    }
+  }
+
+  // 10. crn_ingest_wait waits for the buffer that blocks the push: with more streams than a hand-off can complete, a push is
+  // refused because the FULL fill buffer has open epochs that must move to the other buffer, which is still on the "GPU" — a
+  // caller that waits and pushes again must get through on the first retry (it used to spin: the fill buffer itself was free)
+  {
+    g_fake_gpu_latency_ns = 3000000;
+    Feeder f{16};
+    const int S = 3;
+    REQUIRE(crn_ingest_create(&h, S, 16, 1, &g) == CRN_OK);   // three slots per buffer, a launch per complete epoch
+    std::vector<crn_epoch_result> all;
+    std::vector<long> done(S, 0);
+    std::vector<int> pkt(S, 0);
+    long refusals = 0, worst_retries = 0;
+    // stream 0 runs ten times as fast as the others, so its epochs complete while theirs stay open (holes to carry over)
+    for (int it = 0; it < 600; it++) {
+      const int st = it % 12 < 10 ? 0 : 1 + (it / 12) % 2;
+      std::vector<float> pk = f.packet(st, done[st], pkt[st]);
+      long retries = 0;
+      int rc;
+      while ((rc = crn_ingest_push(g, st, pk.data())) == CRN_ERR_BUSY) {
+        refusals++;
+        retries++;
+        REQUIRE(crn_ingest_wait(g) == CRN_OK);
+        collect(g, &all);
+      }
+      REQUIRE(rc == CRN_OK);
+      if (retries > worst_retries) worst_retries = retries;
+      if (++pkt[st] == 10) { pkt[st] = 0; done[st]++; }
+    }
+    REQUIRE(refusals > 0 && worst_retries == 1);   // one wait is enough, whichever buffer was in the way
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    verify(all, f, S, done);
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    g_fake_gpu_latency_ns = 0;
+  }
   printf("ring_unit: ok\n");
   return 0;
 }

@@ -187,12 +187,15 @@ def run(plan, iq, n_epochs, L=None, epoch_stride=0):
     elif plan.decide == "threshold":
         thr = np.asarray(plan.thresh, dtype=np.float64)[None, :]
         ref = feat[:, plan.ref_band:plan.ref_band + 1] if plan.ref_band >= 0 else 1.0
-        lim = thr * ref
+        # an infinite threshold ("never occupied": the noise-floor band itself) stays infinite whatever it is relative to —
+        # inf x 0 (an empty reference band) would be NaN, and a NaN limit drops the row out of every margin comparison
+        with np.errstate(invalid="ignore"):
+            lim = np.where(np.isinf(thr), np.inf, thr * ref)
         occ = feat > lim
         res["occupancy"] = occ.astype(np.uint8)
         res["decision"] = occ.sum(axis=1).astype(np.int32)
         with np.errstate(divide="ignore", invalid="ignore"):
-            rel = np.where(np.isfinite(lim) & (lim > 0), np.abs(feat / lim - 1.0), np.inf)
+            rel = np.where(np.isfinite(lim) & (lim > 0), np.abs(feat / lim - 1.0), np.inf)   # lim = inf or 0: decided whatever the rounding
         res["margin"] = rel.min(axis=1)
     return res
 

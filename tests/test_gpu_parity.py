@@ -111,6 +111,81 @@ def test_per_bin_error_at_the_stated_floor(built):
             assert g3 < MAG_BOUND[n], line
 
 
+# In-band SNR (dB) up to which the HIP path meets the STATED bar — 1e-5 at floor 1e-3 * mean(E) — on every bin of a driven epoch,
+# per size; beyond it the error grows with the carrier (fp32 dynamic range: the floor is a fixed fraction of a mean the carrier
+# raises, the rounding next to the carrier is a fixed fraction of the carrier) and is held to the fitted line below instead.
+# Measured: profiles/r03_per_bin_error_vs_snr.txt (written by the test from the run itself).
+STATED_BAR_HOLDS_UP_TO_DB = {512: 36, 1024: 36, 2048: 24, 4096: 18}
+SNR_SWEEP_DB = [None, 0, 6, 12, 18, 24, 30, 36]   # None = idle epochs (no carrier)
+
+
+def snr_bound(n, snr_db):
+    """The bar at floor 1e-3 * mean: 1e-5 up to STATED_BAR_HOLDS_UP_TO_DB[n]; above it 1e-5 x 10^((snr - that) / 20) x 1.5 (the error
+    follows the carrier's amplitude once the carrier sets it; 1.5 = headroom over the measured line for other seeds)."""
+    if snr_db is None or snr_db <= STATED_BAR_HOLDS_UP_TO_DB[n]:
+        return 1e-5
+    return 1.5e-5 * 10 ** ((snr_db - STATED_BAR_HOLDS_UP_TO_DB[n]) / 20.0)
+
+
+def test_per_bin_error_against_in_band_snr(built):
+    """the per-bin tolerance stated precisely instead of switched by size.  Idle epochs and driven epochs
+    apart; the driven channel's in-band SNR swept from 0 to +36 dB (carrier power / noise power inside the channel's bins; the
+    headline generator's rms 0.02 is +38 dB at N = 4096); every size; the kernel that answers a spectrum request (all 16 pass-3
+    rows, pass-1 twiddles in their compressed form at N = 4096) and, at 4096, the form with every twiddle read as stored
+    (variant 23).  Asserted: 1e-5 at the stated floor wherever STATED_BAR_HOLDS_UP_TO_DB says so, the fitted line above, and at
+    floor 1e-2 everywhere; never worse than the radix-2 restatement."""
+    import os
+    sigma2 = 1e-6
+    lines = ["N  snr_dB  rms        gpu@1e-3   gpu@1e-2   oracle@1e-3  [v23@1e-3]   bound@1e-3   "
+             "(max over bins and epochs of |E - E64| / max(E64, floor * mean E64); energy mode, K = 10, rectangular)"]
+    fails = []
+    for n in (512, 1024, 2048, 4096):
+        cfg = cs.cfg_energy_scaled(n, 4.0)
+        sensors = [cs.Sensor(cfg)]
+        if n == 4096:
+            sensors.append(cs.Sensor(cfg))
+            sensors[1].set_variant(23)
+        for snr in SNR_SWEEP_DB:
+            worst = {"g3": 0.0, "g2": 0.0, "o3": 0.0, "v3": 0.0}
+            rms_used = 0.0
+            for ch in (1, 2, 3):
+                bins = signals.band_bins(cfg, ch).size
+                rms = 0.0 if snr is None else float(np.sqrt(10 ** (snr / 10.0) * sigma2 * bins / n))
+                rms_used = max(rms_used, rms)
+                n_epochs = 4
+                iq, _ = signals.make_epochs(cfg, n_epochs, seed=31 * n + 7 * ch + (0 if snr is None else snr + 1),
+                                            picks=[0 if snr is None else ch] * n_epochs, signal_rms=max(rms, 1e-30))
+                truth = signals.spectrum_f64(cfg, iq, n_epochs)
+                got = sensors[0].run_host(iq, n_epochs, want_spectrum=True)
+                want = orc.run(cfg, iq, n_epochs, want_spectrum=True)
+                worst["g3"] = max(worst["g3"], per_bin_err(got["spectrum"], truth, 1e-3))
+                worst["g2"] = max(worst["g2"], per_bin_err(got["spectrum"], truth, 1e-2))
+                worst["o3"] = max(worst["o3"], per_bin_err(want["spectrum"], truth, 1e-3))
+                if len(sensors) > 1:
+                    worst["v3"] = max(worst["v3"], per_bin_err(sensors[1].run_host(iq, n_epochs, want_spectrum=True)["spectrum"], truth, 1e-3))
+                if snr is None:
+                    break     # idle epochs do not depend on the channel
+            bound = snr_bound(n, snr)
+            tag = "idle" if snr is None else f"{snr:+d}"
+            lines.append(f"{n:5d} {tag:>5s}  {rms_used:.3e}  {worst['g3']:.3e}  {worst['g2']:.3e}  {worst['o3']:.3e}   "
+                         + (f"{worst['v3']:.3e}" if len(sensors) > 1 else "    -    ") + f"   {bound:.2e}")
+            if not (worst["g3"] < bound):
+                fails.append(lines[-1] + "   <- above the bound at the stated floor")
+            if not (worst["g2"] < PER_BIN_TOL):
+                fails.append(lines[-1] + "   <- above 1e-5 at floor 1e-2")
+            if not (worst["g3"] <= worst["o3"] + 1e-6):
+                fails.append(lines[-1] + "   <- further from float64 than the radix-2 restatement")
+        for sn in sensors:
+            sn.close()
+    lines.append("stated bar (1e-5 at floor 1e-3 * mean) holds for idle epochs at every size and for driven epochs up to: "
+                 + ", ".join(f"N = {n}: {d:+d} dB" for n, d in STATED_BAR_HOLDS_UP_TO_DB.items()))
+    print("\n".join(lines))
+    out_dir = os.environ.get("CRN_EVIDENCE_DIR")
+    if out_dir:
+        open(os.path.join(out_dir, "per_bin_error_vs_snr.txt"), "w").write("\n".join(lines) + "\n")
+    assert not fails, "\n".join(fails)
+
+
 @pytest.mark.parametrize("L", [512, 364, 363, 100])
 def test_reference_mode_matches_oracle(built, L):
     """cfg3: N=512, |X| mean over 10 frames, square of sum, ANN + cascade. L = UHD packet sizes."""
