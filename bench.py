@@ -220,6 +220,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.variant not in (0, 2, 13, 23) and args.variant < 100:
+        os.environ["CRN_SENSE_AB"] = "1"   # measurement variants live in libcrnsense_ab.so, not in the shipped library
     import crnsense as cs
     from sharding import make_device_exchange, shard
 
@@ -276,6 +278,8 @@ def main():
     sensor = cs.Sensor(cfg)
     sensor.set_variant(args.variant)
     info = sensor.kernel_info()
+    if os.environ.get("CRN_SENSE_AB") == "1":
+        workload += " [A/B BUILD libcrnsense_ab.so: measurement variant, not the shipped library]"
     pruned = "PASS3_ROWS" in info["name"]
     if pruned:
         workload += " [kernel specialised to the reference channel plan's 7 of 16 output rows; config.alt.unpruned = any other plan]"

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense.so")  # env override: A/B builds
+# env overrides: CRN_SENSE_LIB = another build of the library; CRN_SENSE_AB=1 = libcrnsense_ab.so, the build that also carries the
+# measurement variants (tools/, the A/B test) — the engine and bench.py's default run use the shipped library
+LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense_ab.so" if os.environ.get("CRN_SENSE_AB") == "1" else "libcrnsense.so")
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
 CRN_ABI_VERSION = 2

@@ -334,6 +334,9 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
     return CRN_OK;
   }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
+  if (!crn::sense_variant_available(variant))
+    return crn::fail(CRN_ERR_ARG, "variant " + std::to_string(variant) + " is a measurement variant: it is compiled into libcrnsense_ab.so "
+                                  "(make -C csrc ab), not into the shipped library");
   h->variant = variant;
   return CRN_OK;
 }
@@ -502,7 +505,11 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   }
   p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;
-  p.ann_out = (c.decide == CRN_DECIDE_ANN || h->variant == 17) ? d_out->ann_out : nullptr;  // 17: trace stamps
+#ifdef CRN_AB_VARIANTS
+  p.ann_out = (c.decide == CRN_DECIDE_ANN || h->variant == 17) ? d_out->ann_out : nullptr;  // 17: the trace build's stamps go there
+#else
+  p.ann_out = c.decide == CRN_DECIDE_ANN ? d_out->ann_out : nullptr;
+#endif
   p.decision = d_out->decision;
   p.occupancy = d_out->occupancy;
   p.spectrum = d_out->spectrum;

@@ -80,6 +80,7 @@ struct SynthParams {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream, bool sc16 = false);
 int sense_num_variants();
+bool sense_variant_available(int variant);   // the shipped library carries 0 (= 13), 2 and 23; libcrnsense_ab.so all of them
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
 struct FftParams {

@@ -24,7 +24,11 @@ namespace crn {
 
 hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream);
 
-// Kernel variants selectable through crn_sense_set_variant (A/B measurements; 0 = default).
+// Kernel variants selectable through crn_sense_set_variant (0 = default).  The shipped library (libcrnsense.so) compiles the three
+// that are forms of the product — 13 (= 0, the default), 2 (no pass-3 row pruning: what any band table outside the reference plan's
+// rows runs anyway) and 23 (every twiddle in registers) — and refuses the others; libcrnsense_ab.so (-DCRN_AB_VARIANTS, used by
+// tools/ and the A/B test) compiles the whole measurement set: other schedules of the same arithmetic, the ablations that compute
+// nothing useful (11, 12, 14, 15, 16, 18) and the trace build (17).
 struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
 static constexpr VariantDesc kVariants[] = {
     /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
@@ -59,6 +63,7 @@ static constexpr int kDefaultVariant = 13;
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
+#ifdef CRN_AB_VARIANTS
   if (win && !mag && p.L == Geo<R3>::N && variant >= 19 && variant <= 22) {
     // A/B set of the windowed kernel: 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2
     // twiddle reads, 21 early twiddle reads alone, 22 the plain windowed kernel
@@ -67,6 +72,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
     if (variant == 21) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kTw2Early>>(p, stream);
     return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase>>(p, stream);
   }
+#endif
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
   // window registers fewer; the A/B numbers are in DESIGN.md §5)
@@ -92,18 +98,23 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   } else {
     // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
     // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.
+#ifdef CRN_AB_VARIANTS
     if (variant == 17 && win && !mag && p.L == Geo<R3>::N)  // measurement aid: close stamps for the windowed / Welch kernel
       return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kSpread | kLdsBlk | kPrioValu | kMulti | kTrace>>(p, stream);
+#endif
     if (win)
       return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
     if (variant == kDefaultVariant && (mag || p.L != Geo<R3>::N))
       return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
     switch (variant) {
+#ifdef CRN_AB_VARIANTS
       case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
+#endif
       case 2:
         if (reg_bands(p))
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
+#ifdef CRN_AB_VARIANTS
       case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
       case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
@@ -117,6 +128,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk>(p, mag, win, stream);
       case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
       case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
+#endif
       case 13:
         // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
         if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
@@ -124,11 +136,13 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
         if (reg_bands(p))
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
+#ifdef CRN_AB_VARIANTS
       case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
       case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
       case 17: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kTrace>(p, mag, win, stream);
       case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
+#endif
       case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
         if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
@@ -151,6 +165,15 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 }
 
 int sense_num_variants() { return kNumVariants; }
+
+// Does this build of the library carry variant v?  (0 = default.)
+bool sense_variant_available(int v) {
+#ifdef CRN_AB_VARIANTS
+  return v >= 0 && v <= kNumVariants;
+#else
+  return v == 0 || v == kDefaultVariant || v == 2 || v == 23;
+#endif
+}
 
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) {
   if (variant < 0 || fft_len != 4096) {  // launch_default: every size / mode other than the 4096-pt plain path

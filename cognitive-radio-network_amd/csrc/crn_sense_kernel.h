@@ -1,0 +1,385 @@
+// crn_sense_kernel.h — the sensing kernel itself (the frame loop in its streaming forms) and its launch helpers.
+#ifndef CRN_SENSE_KERNEL_H
+#define CRN_SENSE_KERNEL_H
+#include "crn_epoch_close.h"
+
+namespace crn {
+// Buffer resource over the IQ window of epoch group `eg` (GROUPS consecutive epochs): anything
+// past the window, or past the end of the batch, reads as zero.
+template <int R3, int SB = 8>
+CRN_DEV __amdgpu_buffer_rsrc_t group_rsrc(const SenseParams &p, long long eg, int span = 1) {
+  using G = Geo<R3>;
+  const long long first = eg * G::GROUPS * p.epoch_stride;
+  long long left = (p.total_samples - first) * SB;
+  const long long window = ((long long)span * G::GROUPS * p.epoch_stride + (long long)p.K * p.frame_stride + G::N) * SB;
+  if (left > window) left = window;
+  if (left < 0) left = 0;
+  char *base = reinterpret_cast<char *>(const_cast<float2 *>(p.iq)) + first * SB;   // p.iq is int16 pairs when SB == 4
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)left, 0x00020000);
+}
+
+// Epoch groups [g0, g0 + n_local) of a streaming workgroup (graded launch: launch_cfg).
+struct StreamSpan {
+  long long g0;
+  int epw, n_local;
+};
+template <int R3>
+CRN_DEV StreamSpan stream_span(const SenseParams &p) {
+  using G = Geo<R3>;
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  const bool big = (long long)blockIdx.x < p.n_big_wgs;
+  StreamSpan s;
+  s.epw = big ? p.groups_per_wg : 1;
+  s.g0 = big ? (long long)blockIdx.x * p.groups_per_wg
+             : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs);
+  s.n_local = (int)((n_groups - s.g0) < s.epw ? (n_groups - s.g0) : s.epw);
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sensing kernel
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p) {
+  constexpr int R3 = C::R3, NBUF = C::NBUF;
+  constexpr bool NT = C::NT, SC = C::SC16;
+  constexpr unsigned SB = C::SB;
+  using G = Geo<R3>;
+  constexpr int T = G::T;
+  extern __shared__ __attribute__((aligned(16))) cx lds[];
+
+  const int tid = threadIdx.x;
+  const int grp = tid / T;
+  const int t = tid % T;       // pass-1 column, n_lo
+  const int a = t / R3;        // pass-2/3 sub-transform id (k mod 16)
+  const int m_lo = t % R3;     // pass-2 column / pass-3 slot g
+
+  FrameCtx<C> c;
+  c.t = t;
+  c.a = a;
+  c.m_lo = m_lo;
+  c.L = p.L;
+  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.grp_epoch_stride = 1;
+  c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
+  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  const int K = p.K;
+  c.Kf = (float)K;
+  c.invK = 1.0f / (float)K;
+
+  // frame-invariant twiddles, kept in registers across frames and epochs
+#pragma unroll
+  for (int i = 1; i < ((C::OPT & kTw1C) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+  if constexpr ((C::OPT & kTw1C) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
+  {
+    // band table -> LDS (2 KiB behind the exchange buffers and the tw2 table): the epoch close walks
+    // it, and from global memory every walk step was a dependent ~1 us vector load
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
+    tab[tid] = p.band_tab[tid];
+    tab[tid + 256] = p.band_tab[tid + 256];
+    if (tid < kBandTabWords - 512) tab[tid + 512] = p.band_tab[tid + 512];  // row entries
+  }
+  if constexpr (C::TW2LDS) {
+    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
+  }
+  __syncthreads();
+  if constexpr (!C::TW2LDS) {
+#pragma unroll
+    for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
+  }
+  if constexpr (C::WIN && (C::OPT & kHannSym) != 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) c.winp[q] = cx{p.window[t + T * (2 * q)], p.window[t + T * (2 * q + 1)]};
+  } else if constexpr (C::WIN) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
+
+  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
+  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * SB;
+  const unsigned fbytes = (unsigned)p.frame_stride * SB;
+
+  cx ua[16], ub[16];
+#ifdef CRN_AB_VARIANTS
+  [[maybe_unused]] cx u0[16];   // ablations that do not re-load: the first frame, kept
+#endif
+
+  if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH && (C::OPT & kMulti) != 0) {
+    if (p.frame_stride * 2 == G::N && p.epoch_stride == (long long)K * (G::N / 2)) {
+      // Welch (hop = N/2) over dense epochs: a lane group's epochs are one uninterrupted stream of
+      // half-frames H(g) = samples [g N/2, (g+1) N/2) — frame g = H(g) | H(g+1), and the half an epoch
+      // ends with is the half the next one starts with.  Three half-frame register sets: two hold the
+      // current frame's raw samples, the third receives H(g+2) while frame g is computed, so every
+      // sample is fetched once per lane group and the prefetch runs across epoch boundaries; the
+      // close fires after every K-th frame.  The workgroup's GROUPS x epw epochs are dealt to its
+      // lane groups in runs of epw (group g: epochs E0 + g epw ...), so that each group's stream is
+      // contiguous; every group runs epw x K frames (the ragged end closes inactive epochs: uniform
+      // barriers, loads past the batch return zero).
+      constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
+      const StreamSpan sp = stream_span<R3>(p);
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, sp.g0, sp.epw);
+      const unsigned voff = (unsigned)(grp * sp.epw * (unsigned)p.epoch_stride + t) * SB;  // shadows the per-epoch one
+      c.grp_epoch_stride = sp.epw;
+      load_frame<R3, NT, SC>(ua, rs, voff, 0u);
+      // Three half-frame sets whose roles rotate (current low half, current high half, incoming):
+      // the loop is unrolled by three so the rotation is a renaming, not 16 register moves a frame.
+      cx ha[16], hb[16], hc[16];  // only [0, 8) of each is used (frame_compute's prefetch target is a cx[16])
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        ha[r] = ua[r];
+        hb[r] = ua[8 + r];
+      }
+      const int F = (G::GROUPS == 1 ? sp.n_local : sp.epw) * K;
+      int f = 0, j = 0, g = 0;
+#define CRN_WELCH_STEP(LO, HI, IN)                                                                  \
+      {                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 8; r++) {                                             \
+          ub[r] = LO[r];                                                                            \
+          ub[8 + r] = HI[r];                                                                        \
+        }                                                                                           \
+        frame_compute<C, true, true>(ub, c, f, &IN, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere); \
+        if (++f == K) {                                                                             \
+          f = 0;                                                                                    \
+          epoch_close<C>(c, p, sp.g0 * G::GROUPS + j);                                              \
+          j++;                                                                                      \
+        }                                                                                           \
+        g++;                                                                                        \
+      }
+      while (g < F) {
+        CRN_WELCH_STEP(ha, hb, hc)
+        if (g >= F) break;
+        CRN_WELCH_STEP(hb, hc, ha)
+        if (g >= F) break;
+        CRN_WELCH_STEP(hc, ha, hb)
+      }
+#undef CRN_WELCH_STEP
+      return;
+    }
+  }
+  {
+    const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
+    const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3, (int)SB>(p, blockIdx.x);
+    load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
+#ifdef CRN_AB_VARIANTS
+    if constexpr (C::ABL >= 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) u0[r] = ua[r];
+    }
+#endif
+    if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH) {
+      if (p.frame_stride * 2 == G::N) {
+        // Welch, hop = N/2: frame f = halves H(f) | H(f+1) with H(j) = samples [j N/2, (j+1) N/2).
+        // Three half-frame register sets: two hold the current frame's raw samples, the third
+        // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
+        // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
+        constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
+        cx h0[8], h1[8], hn[16];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          h0[r] = ua[r];
+          h1[r] = ua[8 + r];
+        }
+        for (int f = 0; f < K; f++) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            ub[r] = h0[r];
+            ub[8 + r] = h1[r];
+          }
+          // H(f+2) is fetched from inside frame f's first pass, one load per radix-4 group
+          frame_compute<C, true, true>(ub, c, f, &hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            h0[r] = h1[r];
+            h1[r] = hn[r];
+          }
+        }
+        epoch_close<C>(c, p, epoch_base);
+        return;
+      }
+    }
+#ifdef CRN_AB_VARIANTS   // frame pairs (kPair) and one epoch group per workgroup: forms the shipped dispatch never selects
+    if constexpr ((C::OPT & kPair) != 0 && C::ABL == 0 && C::NBUF == 2) {
+      // Frame pairs, two pairs per iteration in ping-pong: (ua, ub) and (uc, ud).
+      cx uc[16], ud[16];
+      load_frame<R3, NT, SC>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
+      int f = 0;
+      for (; f + 3 < K; f += 4) {
+        load_frame<R3, NT, SC>(uc, rsrc, voff, (unsigned)(f + 2) * fbytes);
+        load_frame<R3, NT, SC>(ud, rsrc, voff, (unsigned)(f + 3) * fbytes);
+        frame_pair_compute<C>(ua, ub, c);
+        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 4 < K ? (unsigned)(f + 4) * fbytes : kNowhere);
+        load_frame<R3, NT, SC>(ub, rsrc, voff, f + 5 < K ? (unsigned)(f + 5) * fbytes : kNowhere);
+        frame_pair_compute<C>(uc, ud, c);
+      }
+      const int rem = K - f;  // 0..3 frames left, the first two of them already in (ua, ub)
+      if (rem >= 2) {
+        load_frame<R3, NT, SC>(uc, rsrc, voff, rem == 3 ? (unsigned)(f + 2) * fbytes : kNowhere);
+        frame_pair_compute<C>(ua, ub, c);
+        if (rem == 3) {
+          group_sync<C>();
+          frame_compute<C>(uc, c, 0);
+        }
+      } else if (rem == 1) {
+        group_sync<C>();
+        frame_compute<C>(ua, c, 0);
+      }
+      epoch_close<C>(c, p, epoch_base);
+      return;
+    }
+    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) == 0 && C::ABL == 0 && C::PREFETCH) {
+      // One epoch group per workgroup; frame f+1's loads are issued from inside frame f's butterflies.
+      int f = 0;
+      for (; f + 1 < K; f += 2) {
+        frame_compute<C, true>(ua, c, f, &ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+        frame_compute<C, true>(ub, c, f + 1, &ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+      }
+      if (f < K) frame_compute<C>(ua, c, f);
+      epoch_close<C>(c, p, epoch_base);
+      return;
+    }
+#endif
+    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH) {
+      // This workgroup owns p.groups_per_wg consecutive epoch groups and treats their frames as
+      // one stream: twiddles are loaded once, and the first frame of the next epoch is already in
+      // flight while the last frame of this one is computed and closed (the per-workgroup prologue
+      // and the exposed first load cost ~6 % at one epoch per workgroup).  Two register sets in
+      // ping-pong; frame f+1's loads are issued from inside frame f's butterflies.
+      // Workgroups are dispatched in blockIdx order; the last ones take a single epoch group, so the
+      // machine drains in steps of one epoch instead of one 4-epoch workgroup (measured with
+      // s_memrealtime stamps: the last 1024 workgroups used to finish spread over 200 us of a
+      // 1.4 ms kernel).
+      const StreamSpan sp = stream_span<R3>(p);
+      const int epw = sp.epw, n_local = sp.n_local;
+      const long long g0 = sp.g0;
+      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
+      const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
+      load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
+      int j = 0, f = 0;
+#define CRN_STREAM_STEP(CUR, NXT)                                                                   \
+      {                                                                                             \
+        const bool last = f + 1 == K;                                                               \
+        const int j_n = last ? j + 1 : j;                                                           \
+        const int f_n = last ? 0 : f + 1;                                                           \
+        const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
+        frame_compute<C, true>(CUR, c, f, &NXT, rs, voff, soff_n);                                   \
+        if (last) {                                                                                 \
+          epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                               \
+        }                                                                                           \
+        j = j_n;                                                                                    \
+        f = f_n;                                                                                    \
+      }
+      while (true) {
+        CRN_STREAM_STEP(ua, ub)
+        if (j >= n_local) break;
+        CRN_STREAM_STEP(ub, ua)
+        if (j >= n_local) break;
+      }
+#undef CRN_STREAM_STEP
+      return;
+    }
+#ifndef CRN_AB_VARIANTS
+    static_assert((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH,
+                  "shipped kernels are streaming workgroups with the prefetch spread through the butterflies");
+#else
+    if constexpr (C::PREFETCH && C::ABL < 2) {
+      // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
+      // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
+      // last frame they point outside the window and fetch nothing.
+      int f = 0;
+      for (; f + 1 < K; f += 2) {
+        load_frame<R3, NT, SC>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
+        frame_step<C>(ua, c, f, u0);
+        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
+        frame_step<C>(ub, c, f + 1, u0);
+      }
+      if (f < K) frame_step<C>(ua, c, f, u0);
+    } else {
+      for (int f = 0; f < K; f++) {
+        frame_step<C>(ua, c, f, u0);
+        if constexpr (C::ABL < 2)
+          load_frame<R3, NT, SC>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
+      }
+    }
+    epoch_close<C>(c, p, epoch_base);
+#endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch dispatch
+// ---------------------------------------------------------------------------------------------
+template <class C>
+static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
+  using G = Geo<C::R3>;
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  // Welch (hop = N/2) streams when the epochs are dense (see sense_kernel)
+  const bool welch = C::WIN && p.frame_stride * 2 == G::N;
+  const bool welch_stream = welch && p.epoch_stride == (long long)p.K * (G::N / 2);
+  const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
+                     (!welch || welch_stream);
+  SenseParams q = p;
+  unsigned grid;
+  if (multi) {
+    // n_big_wgs workgroups of groups_per_wg groups, then one workgroup per remaining group
+    if (q.n_big_wgs * q.groups_per_wg > n_groups) q.n_big_wgs = n_groups / q.groups_per_wg;
+    grid = (unsigned)(q.n_big_wgs + (n_groups - q.n_big_wgs * q.groups_per_wg));
+  } else {
+    q.n_big_wgs = 0;
+    grid = (unsigned)n_groups;
+  }
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
+  if (grid == 0) return hipSuccess;
+  auto kfn = sense_kernel<C>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, q);
+  return hipGetLastError();
+}
+
+// The register form of the epoch close applies to band plans the host could cut into row entries
+// (crn_api.cpp) when no per-bin spectrum is stored.
+static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
+
+// Default configuration of every size: all mode / window / short-frame combinations.
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti,
+          int WHICH = 0 /* 0 all, 1 unwindowed kernels only, 2 windowed only */>
+static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
+  const bool full = p.L == Geo<R3>::N;
+  const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
+#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
+#define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
+  if constexpr (WHICH != 1) {
+    if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
+    if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
+  }
+  if constexpr (WHICH != 2) {
+    if (regb) {
+      if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
+      if (full) CRN_GO_R(false, false, true);
+      CRN_GO_R(false, false, false);
+    }
+    if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
+    if (full) CRN_GO(false, false, true);
+    CRN_GO(false, false, false);
+  }
+  return hipErrorInvalidValue;
+#undef CRN_GO
+#undef CRN_GO_R
+}
+
+// The plain 4096-point kernel's forms (energy mode, no window, L = N) — the default, its unpruned form, the all-twiddles-in-
+// registers form — and, in the A/B build, the measurement variants.
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL, bool PK, int OPT = 0>
+static hipError_t launch_rn(const SenseParams &p, bool, bool, hipStream_t stream) {
+  return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, false, false, TW2LDS, OCC, ABL, true, PK, OPT>>(p, stream);
+}
+
+
+}  // namespace crn
+#endif

@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd"), os.path.join(ROOT, "tests")]  # run as: python tests/soak_gpu.py [n]
 import torch
+import os as _os
+_os.environ.setdefault("CRN_SENSE_AB", "1")   # measurement variants: libcrnsense_ab.so
 import crnsense as cs, oracle_py as orc, signals
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200

@@ -6,6 +6,8 @@ whether a lighter variant (3 workgroups per CU, no row pruning, ...) holds up be
 import os, sys, statistics as st
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cognitive-radio-network_amd"))
 import torch
+import os as _os
+_os.environ.setdefault("CRN_SENSE_AB", "1")   # measurement variants: libcrnsense_ab.so
 import crnsense as cs
 
 fft = 4096

@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cognitive-radio-network_amd"))
 import numpy as np
 import torch
+import os as _os
+_os.environ.setdefault("CRN_SENSE_AB", "1")   # measurement variants: libcrnsense_ab.so
 import crnsense as cs
 
 cfg = cs.cfg_welch(4096, 8, 64)

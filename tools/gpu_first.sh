@@ -1,4 +1,5 @@
 #!/bin/bash
+export CRN_SENSE_AB=1   # measurement variants are compiled into libcrnsense_ab.so only
 # First GPU session: parity tests, smoke, bench per kernel variant.
 mkdir -p gpurun_out
 rocminfo | grep -E "Marketing|gfx|Compute Unit" | head -6 > gpurun_out/rocminfo.txt 2>&1

@@ -5,6 +5,8 @@ no-close ablation (variant 16).  Interleaved repetitions on one box."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cognitive-radio-network_amd"))
 import torch
+import os as _os
+_os.environ.setdefault("CRN_SENSE_AB", "1")   # measurement variants: libcrnsense_ab.so
 import crnsense as cs
 
 fft = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CRN_SENSE_AB=1   # measurement variants are compiled into libcrnsense_ab.so only
 # Where the 1400 W go: package power and sclk for the ablation variants of the 4096-point kernel
 # (11 stream only, 14 butterflies only, 15 butterflies + LDS exchanges without reload, 16 no epoch close, 0 default).
 probe() {

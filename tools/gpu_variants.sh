@@ -1,4 +1,5 @@
 #!/bin/bash
+export CRN_SENSE_AB=1   # measurement variants are compiled into libcrnsense_ab.so only
 # bench every kernel variant (short) + streaming-read calibration + gpu tests
 mkdir -p gpurun_out
 ./tools/membw > gpurun_out/membw.txt 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CRN_SENSE_AB=1   # measurement variants are compiled into libcrnsense_ab.so only
 # A/B of the windowed-kernel variants on one box (boxes differ by a few %: only numbers of one call compare).
 for rep in 1 2; do
 for v in ${VARIANTS:-22 19 20 21 0}; do
