@@ -496,11 +496,50 @@ def main():
             ms = [a.elapsed_time(b) for a, b in pairs]
             gbs = epochs * spe * 8 / (float(np.mean(ms)) * 1e-3) / 1e9
             return {"epochs": epochs, "bytes_per_step": epochs * spe * 8, "kernel_ms_mean": float(np.mean(ms)),
-                    "kernel_ms_median": float(np.median(ms)), "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+                    "kernel_ms_median": float(np.median(ms)), "kernel_ms_min": float(np.min(ms)), "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
                     "Msamples/s": epochs * spe / (float(np.mean(ms)) * 1e-3) / 1e6}
+
+        def leg_two_streams(sn, epochs, n=60):
+            """Consecutive batches launched alternately on two streams: a launch's ramp and its last, partly filled round of
+            workgroups overlap the neighbouring launch instead of leaving the machine part empty (launches on ONE stream
+            serialise: the next kernel waits for the previous one's last workgroup).  Batches are independent — no state crosses
+            epochs — so this is how a caller with a queue of batches runs them.  Timed as a span: first launch to the last
+            event on either stream; 4 disjoint output sets so that launches in flight never share a buffer."""
+            sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            sets = []
+            for _ in range(4):
+                t = [torch.empty(epochs, cfg.n_bands, dtype=torch.float32, device=dev), torch.empty(epochs, 3, dtype=torch.float64, device=dev),
+                     torch.empty(epochs, dtype=torch.int32, device=dev), torch.empty(epochs, cfg.n_bands, dtype=torch.uint8, device=dev)]
+                sets.append((t, {"features": t[0].data_ptr(), "ann_out": t[1].data_ptr(), "decision": t[2].data_ptr(),
+                                 "occupancy": t[3].data_ptr(), "spectrum": 0}))
+            torch.cuda.synchronize()
+
+            def burst(count):
+                for i in range(count):
+                    st = (sa, sb)[i & 1]
+                    sn.run_device(iq.data_ptr(), epochs, N, sets[i & 3][1], stream=st.cuda_stream)
+            burst(max(20, int(0.03 / 1.6e-3 * E / epochs)))
+            torch.cuda.synchronize()
+            e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(sa)
+            sb.wait_event(e0)
+            burst(n)
+            ea.record(sa)
+            eb.record(sb)
+            torch.cuda.synchronize()
+            span_ms = max(e0.elapsed_time(ea), e0.elapsed_time(eb))
+            same = all(torch.equal(a, b) for a, b in zip(sets[0][0], sets[1][0]))   # same input, same kernel: identical outputs
+            gbs = epochs * spe * 8 * n / (span_ms * 1e-3) / 1e9
+            return {"epochs": epochs, "bytes_per_step": epochs * spe * 8, "launches": n, "span_ms": span_ms, "ms_per_launch": span_ms / n,
+                    "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "Msamples/s": epochs * spe * n / (span_ms * 1e-3) / 1e6,
+                    "outputs_identical_across_streams": bool(same)}
         e2g = (2 ** 28) // spe   # SURVEY.md §8(d) cfgH: B = 2^28 / 4096 = 65 536 frames = 2 GiB
         alt = {"cfgH_2GiB_batch": dict(leg(sensor, e2g), kernel=info["name"][:40] + "...",
-                                       note="SURVEY.md §8(d) cfgH batch: 2^28 samples per launch (launch ramp and tail weigh more)")}
+                                       note="SURVEY.md §8(d) cfgH batch: 2^28 samples per launch (launch ramp and tail weigh more); launches "
+                                            "on one stream, one event pair per launch")}
+        alt["cfgH_2GiB_batch_two_streams"] = dict(leg_two_streams(sensor, e2g), kernel=info["name"][:40] + "...",
+                                                  note="the same 2 GiB batches launched alternately on two streams, so that one launch's "
+                                                       "ramp and partly filled last round overlap its neighbour (span over 60 launches / 60)")
         s2 = cs.Sensor(cfg)
         s2.set_variant(2)
         alt["unpruned"] = dict(leg(s2, E), kernel=s2.kernel_info()["name"],

@@ -33,7 +33,8 @@ struct crn_handle {
   crn_cfg cfg;
   int variant = 0;
   int groups_per_wg = 0;        // 0 = automatic
-  int64_t tail_groups = -1;     // < 0 = automatic; epoch groups handed to single-group workgroups at the end
+  int64_t tail_groups = -1;     // < 0 = automatic; epoch groups handed to the short tail workgroups at the end
+  int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
@@ -329,8 +330,12 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
     h->groups_per_wg = variant - 100;
     return CRN_OK;
   }
-  if (variant >= 200 && variant <= 264) {  // A/B: 200 + n = n x 256 epoch groups in single-group tail workgroups
+  if (variant >= 200 && variant <= 264) {  // A/B: 200 + n = n x 256 epoch groups in the short tail workgroups
     h->tail_groups = (int64_t)(variant - 200) * 256;
+    return CRN_OK;
+  }
+  if (variant >= 300 && variant <= 364) {  // A/B: 300 + n = n epoch groups per tail workgroup (300 = automatic)
+    h->tail_groups_per_wg = variant - 300;
     return CRN_OK;
   }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
@@ -481,6 +486,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     int64_t tail = h->tail_groups >= 0 ? h->tail_groups : 1024;  // one per workgroup slot (256 CUs x 4): +0.9 % at N = 4096
     if (tail > n_groups / 4) tail = n_groups / 4;
     p.n_big_wgs = (n_groups - tail) / p.groups_per_wg;
+    p.tail_groups_per_wg = h->tail_groups_per_wg > 0 ? h->tail_groups_per_wg : 1;
   }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;

@@ -12,6 +12,9 @@ namespace crn {
 // (v_pk_add/mul/fma_f32) work on it directly.
 typedef float cx __attribute__((ext_vector_type(2)));
 #define CRN_DEV static __device__ __forceinline__
+// the transforms below also compile for the host (their scalar form, PK = false): tests/harness/butterfly_unit.cpp checks the
+// algebra against a double-precision DFT without a GPU
+#define CRN_HD static __host__ __device__ __forceinline__
 
 // ---------------------------------------------------------------------------------------------
 // Complex arithmetic, forward transform convention W = exp(-j theta).
@@ -26,28 +29,32 @@ typedef float cx __attribute__((ext_vector_type(2)));
 // LOW result, op_sel_hi[i] the half feeding the HIGH result; neg_lo / neg_hi negate source i for
 // the low / high result.
 // ---------------------------------------------------------------------------------------------
+#define CRN_C1 0.92387953251128674f  // cos(pi/8)
+#define CRN_S1 0.38268343236508977f  // sin(pi/8)
+#define CRN_H_ 0.70710678118654752f  // sqrt(1/2)
+
 template <bool PK>
 struct M {
-  CRN_DEV cx add(cx a, cx b) {
+  CRN_HD cx add(cx a, cx b) {
     if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
     else return cx{a.x + b.x, a.y + b.y};
   }
-  CRN_DEV cx sub(cx a, cx b) {
+  CRN_HD cx sub(cx a, cx b) {
     if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
     else return cx{a.x - b.x, a.y - b.y};
   }
   // a + (-j) b = (a.x + b.y, a.y - b.x)
-  CRN_DEV cx add_mj(cx a, cx b) {
+  CRN_HD cx add_mj(cx a, cx b) {
     if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
     else return cx{a.x + b.y, a.y - b.x};
   }
   // a - (-j) b = (a.x - b.y, a.y + b.x)
-  CRN_DEV cx sub_mj(cx a, cx b) {
+  CRN_HD cx sub_mj(cx a, cx b) {
     if constexpr (PK) { cx d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
     else return cx{a.x - b.y, a.y + b.x};
   }
   // a * w, w in VGPRs (per-lane twiddle)
-  CRN_DEV cx mul(cx a, cx w) {
+  CRN_HD cx mul(cx a, cx w) {
     if constexpr (PK) {
       cx t, d;
       asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));  // (a.x w.x, a.y w.x)
@@ -59,7 +66,7 @@ struct M {
     }
   }
   // a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
-  CRN_DEV cx mul_conj(cx a, cx w) {
+  CRN_HD cx mul_conj(cx a, cx w) {
     if constexpr (PK) {
       cx t, d;
       asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
@@ -72,7 +79,7 @@ struct M {
   }
   // w_S * t + x (NEG: w_S * t - x), w_S = half S of the register pair wp: a real weight applied to a complex value
   template <int S, bool NEG>
-  CRN_DEV cx fma_w(cx wp, cx t, cx x) {
+  CRN_HD cx fma_w(cx wp, cx t, cx x) {
     if constexpr (PK) {
       cx d;
       if constexpr (S == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(wp), "v"(t), "v"(x));
@@ -85,8 +92,38 @@ struct M {
       return NEG ? cx{fmaf(w, t.x, -x.x), fmaf(w, t.y, -x.y)} : cx{fmaf(w, t.x, x.x), fmaf(w, t.y, x.y)};
     }
   }
+  // The twiddles W16^2 = sqrt(1/2) (1 - j), W16^6 = -sqrt(1/2) (1 + j) (and W8^1, W8^3) are not multiplied out: (1 -+ j) a is one
+  // packed add of a with itself rotated (add_mj / sub_mj below), and the factor h = sqrt(1/2) rides in the FMA that consumes the
+  // product — x +- h u instead of x +- (u * w): one packed add + the FMA where a complex multiply (two packed instructions, four
+  // real multiplies) + an add stood.  4 packed instructions fewer per 16-point transform, 12 of the ~334 of a 4096-point frame.
+  //   fma_h(u, x) = x + h u      fms_h(u, x) = x - h u      fma_h_mj(u, x) = x + (-j) h u      fms_h_mj(u, x) = x - (-j) h u
+  // (h comes as an SGPR pair (h, h); neg_* on source 1 flips the sign of h for one or both halves)
+  CRN_HD cx fma_h(cx u, cx x) {
+    if constexpr (PK) { cx d; const cx h = {CRN_H_, CRN_H_}; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(u), "s"(h), "v"(x)); return d; }
+    else return cx{fmaf(CRN_H_, u.x, x.x), fmaf(CRN_H_, u.y, x.y)};
+  }
+  CRN_HD cx fms_h(cx u, cx x) {
+    if constexpr (PK) { cx d; const cx h = {CRN_H_, CRN_H_}; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(u), "s"(h), "v"(x)); return d; }
+    else return cx{fmaf(-CRN_H_, u.x, x.x), fmaf(-CRN_H_, u.y, x.y)};
+  }
+  // x + (-j) h u = (x.x + h u.y, x.y - h u.x)
+  CRN_HD cx fma_h_mj(cx u, cx x) {
+    if constexpr (PK) {
+      cx d; const cx h = {CRN_H_, CRN_H_};
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(u), "s"(h), "v"(x));
+      return d;
+    } else return cx{fmaf(CRN_H_, u.y, x.x), fmaf(-CRN_H_, u.x, x.y)};
+  }
+  // x - (-j) h u = (x.x - h u.y, x.y + h u.x)
+  CRN_HD cx fms_h_mj(cx u, cx x) {
+    if constexpr (PK) {
+      cx d; const cx h = {CRN_H_, CRN_H_};
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(u), "s"(h), "v"(x));
+      return d;
+    } else return cx{fmaf(-CRN_H_, u.y, x.x), fmaf(CRN_H_, u.x, x.y)};
+  }
   // a * w, w a wave-uniform constant held in an SGPR pair
-  CRN_DEV cx mul_c(cx a, cx w) {
+  CRN_HD cx mul_c(cx a, cx w) {
     if constexpr (PK) {
       cx t, d;
       asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
@@ -101,24 +138,21 @@ struct M {
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <int I, int N, class F>
-CRN_DEV void static_for_(F &f) {
+CRN_HD void static_for_(F &f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
     static_for_<I + 1, N>(f);
   }
 }
 template <int N, class F>
-CRN_DEV void static_for(F &&f) {
+CRN_HD void static_for(F &&f) {
   static_for_<0, N>(f);
 }
 
-#define CRN_C1 0.92387953251128674f  // cos(pi/8)
-#define CRN_S1 0.38268343236508977f  // sin(pi/8)
-#define CRN_H 0.70710678118654752f   // sqrt(1/2)
 
 // 4-point forward DFT in place.  B2MJ: input a2 still lacks a factor -j (a folded W16^4 / W8^2).
 template <bool PK, bool B2MJ = false>
-CRN_DEV void dft4(cx &a0, cx &a1, cx &a2, cx &a3) {
+CRN_HD void dft4(cx &a0, cx &a1, cx &a2, cx &a3) {
   using m = M<PK>;
   const cx s02 = B2MJ ? m::add_mj(a0, a2) : m::add(a0, a2);
   const cx d02 = B2MJ ? m::sub_mj(a0, a2) : m::sub(a0, a2);
@@ -130,32 +164,50 @@ CRN_DEV void dft4(cx &a0, cx &a1, cx &a2, cx &a3) {
 }
 
 struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
+  __host__ __device__ __forceinline__ void operator()(int) const {}
 };
 
 // Twiddles W16^{r0 a0} and level B of the 16-point transform (shared by the plain and the windowed level A).
 template <bool PK, class Hook = NoHook>
-CRN_DEV void dft16_level_b(cx (&y)[16], cx (&out)[16], const Hook &hook = Hook()) {
+CRN_HD void dft16_level_b(cx (&y)[16], cx (&out)[16], const Hook &hook = Hook()) {
   using m = M<PK>;
-  // W16^{r0 a0} on element (r0, a0) = y[r0 + 4 a0]; W16^4 = -j is folded into level B
-  const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
-  const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
-  y[1 + 4 * 1] = m::mul_c(y[1 + 4 * 1], w1);
-  y[1 + 4 * 2] = m::mul_c(y[1 + 4 * 2], w2);
-  y[1 + 4 * 3] = m::mul_c(y[1 + 4 * 3], w3);
-  y[2 + 4 * 1] = m::mul_c(y[2 + 4 * 1], w2);
-  y[2 + 4 * 3] = m::mul_c(y[2 + 4 * 3], w6);
-  y[3 + 4 * 1] = m::mul_c(y[3 + 4 * 1], w3);
-  y[3 + 4 * 2] = m::mul_c(y[3 + 4 * 2], w6);
-  y[3 + 4 * 3] = m::mul_c(y[3 + 4 * 3], w9);
-  // level B: for each a0, DFT4 over r0; X[a0 + 4 a1] = y[a1 + 4 a0]
-  dft4<PK>(y[0], y[1], y[2], y[3]);
+  // W16^{r0 a0} on element (a0, r0) = y[r0 + 4 a0], then for each a0 a DFT4 over r0; X[a0 + 4 a1] = y[a1 + 4 a0].
+  // W16^4 = -j is folded into the butterfly; W16^2 and W16^6 are (1 - j) / -(1 + j) times h = sqrt(1/2): one rotated add each, h
+  // applied by the FMAs that consume them (see M::fma_h).  W16^1, W16^3, W16^9 are multiplied out.
+  const cx w1 = {CRN_C1, -CRN_S1}, w3 = {CRN_S1, -CRN_C1}, w9 = {-CRN_C1, CRN_S1};
+  dft4<PK>(y[0], y[1], y[2], y[3]);                      // a0 = 0: no twiddles
   hook(4);
-  dft4<PK>(y[4], y[5], y[6], y[7]);
+  {                                                      // a0 = 1: W16^1, W16^2 = h (1 - j), W16^3
+    const cx b0 = y[4], b1 = m::mul_c(y[5], w1), b3 = m::mul_c(y[7], w3);
+    const cx p = m::add_mj(y[6], y[6]);                  // (1 - j) y
+    const cx s02 = m::fma_h(p, b0), d02 = m::fms_h(p, b0);
+    const cx s13 = m::add(b1, b3), d13 = m::sub(b1, b3);
+    y[4] = m::add(s02, s13);
+    y[6] = m::sub(s02, s13);
+    y[5] = m::add_mj(d02, d13);
+    y[7] = m::sub_mj(d02, d13);
+  }
   hook(5);
-  dft4<PK, true>(y[8], y[9], y[10], y[11]);  // y[10] carries the folded -j
+  {                                                      // a0 = 2: W16^2 = h (1 - j), W16^4 = -j, W16^6 = -h (1 + j)
+    const cx p = m::add_mj(y[9], y[9]), q = m::sub_mj(y[11], y[11]);   // (1 - j) y1, (1 + j) y3
+    const cx s02 = m::add_mj(y[8], y[10]), d02 = m::sub_mj(y[8], y[10]);
+    const cx u = m::sub(p, q), v = m::add(p, q);         // s13 = h u, d13 = h v
+    y[8] = m::fma_h(u, s02);
+    y[10] = m::fms_h(u, s02);
+    y[9] = m::fma_h_mj(v, d02);
+    y[11] = m::fms_h_mj(v, d02);
+  }
   hook(6);
-  dft4<PK>(y[12], y[13], y[14], y[15]);
+  {                                                      // a0 = 3: W16^3, W16^6 = -h (1 + j), W16^9
+    const cx b0 = y[12], b1 = m::mul_c(y[13], w3), b3 = m::mul_c(y[15], w9);
+    const cx q = m::sub_mj(y[14], y[14]);                // (1 + j) y
+    const cx s02 = m::fms_h(q, b0), d02 = m::fma_h(q, b0);
+    const cx s13 = m::add(b1, b3), d13 = m::sub(b1, b3);
+    y[12] = m::add(s02, s13);
+    y[14] = m::sub(s02, s13);
+    y[13] = m::add_mj(d02, d13);
+    y[15] = m::sub_mj(d02, d13);
+  }
   hook(7);
 #pragma unroll
   for (int a0 = 0; a0 < 4; a0++)
@@ -166,7 +218,7 @@ CRN_DEV void dft16_level_b(cx (&y)[16], cx (&out)[16], const Hook &hook = Hook()
 // 16-point forward DFT, natural order in and out, as 4 x 4.  `hook(k)`, k = 0..7, runs after the
 // k-th radix-4 group: the caller uses it to drop one prefetch load into the butterfly stream.
 template <bool PK, class Hook = NoHook>
-CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook()) {
+CRN_HD void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook()) {
   cx y[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) y[i] = in[i];
@@ -186,7 +238,7 @@ CRN_DEV void dft16(const cx (&in)[16], cx (&out)[16], const Hook &hook = Hook())
 // — two packed adds and two packed FMAs per pair, the cycles of the 4 multiplies + 2 adds they replace in
 // a third fewer instructions, and 8 window registers instead of 16.  wp[p] = (w[2p], w[2p + 1]), rows 0..7.
 template <bool PK, class Hook = NoHook>
-CRN_DEV void dft16_hann(const cx (&in)[16], cx (&out)[16], const cx (&wp)[4], const Hook &hook = Hook()) {
+CRN_HD void dft16_hann(const cx (&in)[16], cx (&out)[16], const cx (&wp)[4], const Hook &hook = Hook()) {
   using m = M<PK>;
   cx y[16];
 #pragma unroll
@@ -218,56 +270,74 @@ static constexpr unsigned kRefPlanRows = 0x8267u;  // rows {0, 1, 2, 5, 6, 9, 15
 
 // DFT16 whose last level only forms the outputs named in MASK (bit d = X[d] needed).
 template <bool PK, unsigned MASK>
-CRN_DEV void dft16_pruned(const cx (&in)[16], cx (&out)[16]) {
+CRN_HD void dft16_pruned(const cx (&in)[16], cx (&out)[16]) {
   using m = M<PK>;
   cx y[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) y[i] = in[i];
 #pragma unroll
   for (int r0 = 0; r0 < 4; r0++) dft4<PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
-  const cx w1 = {CRN_C1, -CRN_S1}, w2 = {CRN_H, -CRN_H}, w3 = {CRN_S1, -CRN_C1};
-  const cx w6 = {-CRN_H, -CRN_H}, w9 = {-CRN_C1, CRN_S1};
-  y[1 + 4 * 1] = m::mul_c(y[1 + 4 * 1], w1);
-  y[1 + 4 * 2] = m::mul_c(y[1 + 4 * 2], w2);
-  y[1 + 4 * 3] = m::mul_c(y[1 + 4 * 3], w3);
-  y[2 + 4 * 1] = m::mul_c(y[2 + 4 * 1], w2);
-  y[2 + 4 * 3] = m::mul_c(y[2 + 4 * 3], w6);
-  y[3 + 4 * 1] = m::mul_c(y[3 + 4 * 1], w3);
-  y[3 + 4 * 2] = m::mul_c(y[3 + 4 * 2], w6);
-  y[3 + 4 * 3] = m::mul_c(y[3 + 4 * 3], w9);
-#pragma unroll
-  for (int a0 = 0; a0 < 4; a0++) {
-    constexpr unsigned M0 = MASK;
-    const bool n0 = (M0 >> (a0 + 0)) & 1, n1 = (M0 >> (a0 + 4)) & 1, n2 = (M0 >> (a0 + 8)) & 1, n3 = (M0 >> (a0 + 12)) & 1;
-    const cx b0 = y[4 * a0], b1 = y[4 * a0 + 1], b2 = y[4 * a0 + 2], b3 = y[4 * a0 + 3];
-    cx s02 = b0, d02 = b0, s13 = b1, d13 = b1;
-    if (n0 || n2) { s02 = a0 == 2 ? m::add_mj(b0, b2) : m::add(b0, b2); s13 = m::add(b1, b3); }
-    if (n1 || n3) { d02 = a0 == 2 ? m::sub_mj(b0, b2) : m::sub(b0, b2); d13 = m::sub(b1, b3); }
-    if (n0) out[a0 + 0] = m::add(s02, s13);
-    if (n1) out[a0 + 4] = m::add_mj(d02, d13);
-    if (n2) out[a0 + 8] = m::sub(s02, s13);
-    if (n3) out[a0 + 12] = m::sub_mj(d02, d13);
-  }
+  // level B as in dft16_level_b (same twiddle forms, same roundings for the outputs that are formed), output d = a0 + 4 a1 only when
+  // MASK names it: out[a0] / out[a0 + 8] need (s02, s13), out[a0 + 4] / out[a0 + 12] need (d02, d13)
+  const cx w1 = {CRN_C1, -CRN_S1}, w3 = {CRN_S1, -CRN_C1}, w9 = {-CRN_C1, CRN_S1};
+  static_for<4>([&](auto ac) {
+    constexpr int a0 = decltype(ac)::value;
+    constexpr bool n0 = (MASK >> (a0 + 0)) & 1, n1 = (MASK >> (a0 + 4)) & 1, n2 = (MASK >> (a0 + 8)) & 1, n3 = (MASK >> (a0 + 12)) & 1;
+    constexpr bool S = n0 || n2, D = n1 || n3;
+    const cx b0 = y[4 * a0];
+    if constexpr (a0 == 2) {   // W16^2 = h (1 - j), W16^4 = -j, W16^6 = -h (1 + j): s13 = h u, d13 = h v
+      const cx p = m::add_mj(y[9], y[9]), q = m::sub_mj(y[11], y[11]);
+      if constexpr (S) {
+        const cx s02 = m::add_mj(b0, y[10]), u = m::sub(p, q);
+        if constexpr (n0) out[a0 + 0] = m::fma_h(u, s02);
+        if constexpr (n2) out[a0 + 8] = m::fms_h(u, s02);
+      }
+      if constexpr (D) {
+        const cx d02 = m::sub_mj(b0, y[10]), v = m::add(p, q);
+        if constexpr (n1) out[a0 + 4] = m::fma_h_mj(v, d02);
+        if constexpr (n3) out[a0 + 12] = m::fms_h_mj(v, d02);
+      }
+    } else {
+      cx b1 = y[4 * a0 + 1], b3 = y[4 * a0 + 3];
+      if constexpr (a0 == 1) { b1 = m::mul_c(b1, w1); b3 = m::mul_c(b3, w3); }
+      if constexpr (a0 == 3) { b1 = m::mul_c(b1, w3); b3 = m::mul_c(b3, w9); }
+      const cx r = a0 == 1 ? m::add_mj(y[4 * a0 + 2], y[4 * a0 + 2]) : a0 == 3 ? m::sub_mj(y[4 * a0 + 2], y[4 * a0 + 2]) : y[4 * a0 + 2];
+      if constexpr (S) {
+        const cx s02 = a0 == 0 ? m::add(b0, r) : a0 == 1 ? m::fma_h(r, b0) : m::fms_h(r, b0);
+        const cx s13 = m::add(b1, b3);
+        if constexpr (n0) out[a0 + 0] = m::add(s02, s13);
+        if constexpr (n2) out[a0 + 8] = m::sub(s02, s13);
+      }
+      if constexpr (D) {
+        const cx d02 = a0 == 0 ? m::sub(b0, r) : a0 == 1 ? m::fms_h(r, b0) : m::fma_h(r, b0);
+        const cx d13 = m::sub(b1, b3);
+        if constexpr (n1) out[a0 + 4] = m::add_mj(d02, d13);
+        if constexpr (n3) out[a0 + 12] = m::sub_mj(d02, d13);
+      }
+    }
+  });
 }
 
 // 8-point forward DFT as 2 x 4.
 template <bool PK>
-CRN_DEV void dft8(const cx (&in)[8], cx (&out)[8]) {
+CRN_HD void dft8(const cx (&in)[8], cx (&out)[8]) {
   using m = M<PK>;
   cx y[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) y[i] = in[i];
   dft4<PK>(y[0], y[2], y[4], y[6]);  // r = r0 + 2 r1: DFT4 over r1 -> a0 at y[r0 + 2 a0]
   dft4<PK>(y[1], y[3], y[5], y[7]);
-  const cx w1 = {CRN_H, -CRN_H}, w3 = {-CRN_H, -CRN_H};
-  y[3] = m::mul_c(y[3], w1);  // W8^1 on (r0 = 1, a0 = 1)
-  y[7] = m::mul_c(y[7], w3);  // W8^3 on (r0 = 1, a0 = 3); W8^2 = -j on y[5] folded below
-#pragma unroll
-  for (int a0 = 0; a0 < 4; a0++) {
-    const cx e = y[2 * a0], o = y[2 * a0 + 1];
-    out[a0] = a0 == 2 ? m::add_mj(e, o) : m::add(e, o);
-    out[a0 + 4] = a0 == 2 ? m::sub_mj(e, o) : m::sub(e, o);
-  }
+  // W8^1 = h (1 - j) on (r0 = 1, a0 = 1), W8^3 = -h (1 + j) on (r0 = 1, a0 = 3): a rotated add, h applied by the FMA (M::fma_h);
+  // W8^2 = -j on y[5] folded into its butterfly
+  const cx p = m::add_mj(y[3], y[3]), q = m::sub_mj(y[7], y[7]);
+  out[0] = m::add(y[0], y[1]);
+  out[4] = m::sub(y[0], y[1]);
+  out[1] = m::fma_h(p, y[2]);
+  out[5] = m::fms_h(p, y[2]);
+  out[2] = m::add_mj(y[4], y[5]);
+  out[6] = m::sub_mj(y[4], y[5]);
+  out[3] = m::fms_h(q, y[6]);
+  out[7] = m::fma_h(q, y[6]);
 }
 
 }  // namespace crn

@@ -22,8 +22,10 @@ struct SenseParams {
   int L;                   // samples taken per frame (zero-padded to N)
   int K;                   // frames per epoch
   int groups_per_wg;       // consecutive epoch groups one workgroup streams through (>= 1)
-  long long n_big_wgs;     // workgroups [0, n_big_wgs) take groups_per_wg groups each; the ones after them one
-                           // group each (they are dispatched last: the end of the kernel drains in small steps)
+  long long n_big_wgs;     // workgroups [0, n_big_wgs) take groups_per_wg groups each; the ones after them
+                           // tail_groups_per_wg each (they are dispatched last: the end of the kernel drains in small steps)
+  int tail_groups_per_wg;  // >= 1 (1 for the plain kernels; the Welch stream, which re-reads one half-frame per workgroup span,
+                           // keeps its tail workgroups longer)
   // tables (device, built at crn_sense_create)
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}

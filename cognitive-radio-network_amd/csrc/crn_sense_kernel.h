@@ -29,9 +29,9 @@ CRN_DEV StreamSpan stream_span(const SenseParams &p) {
   const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
   const bool big = (long long)blockIdx.x < p.n_big_wgs;
   StreamSpan s;
-  s.epw = big ? p.groups_per_wg : 1;
+  s.epw = big ? p.groups_per_wg : p.tail_groups_per_wg;
   s.g0 = big ? (long long)blockIdx.x * p.groups_per_wg
-             : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs);
+             : p.n_big_wgs * p.groups_per_wg + ((long long)blockIdx.x - p.n_big_wgs) * p.tail_groups_per_wg;
   s.n_local = (int)((n_groups - s.g0) < s.epw ? (n_groups - s.g0) : s.epw);
   return s;
 }
@@ -323,11 +323,13 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   SenseParams q = p;
   unsigned grid;
   if (multi) {
-    // n_big_wgs workgroups of groups_per_wg groups, then one workgroup per remaining group
+    // n_big_wgs workgroups of groups_per_wg groups, then workgroups of tail_groups_per_wg over the remaining groups
+    if (q.tail_groups_per_wg < 1) q.tail_groups_per_wg = 1;
     if (q.n_big_wgs * q.groups_per_wg > n_groups) q.n_big_wgs = n_groups / q.groups_per_wg;
-    grid = (unsigned)(q.n_big_wgs + (n_groups - q.n_big_wgs * q.groups_per_wg));
+    grid = (unsigned)(q.n_big_wgs + (n_groups - q.n_big_wgs * q.groups_per_wg + q.tail_groups_per_wg - 1) / q.tail_groups_per_wg);
   } else {
     q.n_big_wgs = 0;
+    q.tail_groups_per_wg = 1;
     grid = (unsigned)n_groups;
   }
   const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;

@@ -48,7 +48,11 @@ def test_bench_default_batch_with_every_alt_leg_and_the_cpu_check(built):
     samples) — and the CPU sample check after them still reads the headline launch's results, not a leg's."""
     d = _run("--cpu-epochs", "64", epochs=())
     alt = d["config"]["alt"]
-    assert set(alt) == {"cfgH_2GiB_batch", "unpruned", "adc16_input", "wire_format_sc16"}
+    assert set(alt) == {"cfgH_2GiB_batch", "cfgH_2GiB_batch_two_streams", "unpruned", "adc16_input", "wire_format_sc16"}
+    two = alt.pop("cfgH_2GiB_batch_two_streams")
+    assert two["outputs_identical_across_streams"] and two["launches"] == 60 and 0.3 < two["frac"] < 1.0
+    assert two["bytes_per_step"] == alt["cfgH_2GiB_batch"]["bytes_per_step"]
+    assert alt["cfgH_2GiB_batch"]["kernel_ms_min"] <= alt["cfgH_2GiB_batch"]["kernel_ms_mean"]
     assert alt["wire_format_sc16"]["bytes_per_step"] * 2 == alt["adc16_input"]["bytes_per_step"]
     assert alt["wire_format_sc16"]["Msamples/s"] > alt["adc16_input"]["Msamples/s"]
     for leg in alt.values():

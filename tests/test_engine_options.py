@@ -130,17 +130,18 @@ def test_trained_weights_reach_the_engine_through_a_file(built, tmp_path, n_fft)
     import torch
     dev = torch.device("cuda", 0)
     cfg = cs.cfg_reference_scaled(n_fft)   # (DECIDE_ANN with the shipped weights: only the features of this launch are used)
-    spe = cs.samples_per_epoch(cfg)
+    L, rms = 364, 0.002                    # the radio's packets; a carrier 20 dB below the level the shipped weights were fitted for
+    spe = cs.samples_per_epoch(cfg, L)
     n_train = 2048
     s = cs.Sensor(cfg)
     iq = torch.zeros(n_train * spe * 2, dtype=torch.float32, device=dev)
     truth = torch.zeros(n_train, dtype=torch.int32, device=dev)
     feat = torch.zeros(n_train, 4, dtype=torch.float32, device=dev)
     sc = cs.SynthCfg()
-    sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 31337, 1e-6, 0.02, 8
+    sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 31337, 1e-6, rms, 8
     sc.pu_model, sc.signal_kind, sc.n_streams = cs.PU_UNIFORM, cs.SIG_TONES, 1
     s.synth_fill_device_ex(iq.data_ptr(), n_train, spe, sc, truth_ptr=truth.data_ptr())
-    s.run_device(iq.data_ptr(), n_train, n_fft, {"features": feat.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0})
+    s.run_device(iq.data_ptr(), n_train, L, {"features": feat.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": 0, "spectrum": 0})
     tc = cs.TrainCfg()
     tc.seed, tc.iterations, tc.restarts, tc.eta, tc.alpha, tc.normalise = 1, 400, 4, 2.0, 0.9, 1
     wih, who, loss = s.ann_train_device(tc, feat.data_ptr(), truth.data_ptr(), n_train)
@@ -153,8 +154,8 @@ def test_trained_weights_reach_the_engine_through_a_file(built, tmp_path, n_fft)
     assert all(back.ann_w_ih[i][j] == fitted.ann_w_ih[i][j] for i in range(5) for j in range(6))      # exact round trip
     assert all(back.ann_w_ho[j][k] == fitted.ann_w_ho[j][k] for j in range(6) for k in range(4))
 
-    L, n_epochs = 364, 24
-    test_iq, picks = signals.make_epochs(fitted, n_epochs, seed=99, L=L)
+    n_epochs = 24
+    test_iq, picks = signals.make_epochs(fitted, n_epochs, seed=99, L=L, signal_rms=rms)
     out = _run_harness("engine_harness", ["IQ", str(L), "-g", "0", "-v", "0", "-n", str(n_fft), "-w", str(wfile)], tmp_path, test_iq)
     full, _ = _epoch_lines(out)
     assert len(full) == n_epochs

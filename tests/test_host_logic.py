@@ -35,6 +35,17 @@ def test_engine_control_flow_under_thread_sanitizer(built):
     _run_unit("engine_unit", 2)
 
 
+def test_butterfly_algebra_on_the_host(built):
+    """tests/harness/butterfly_unit.cpp: the 4 / 8 / 16-point transforms of csrc/crn_butterflies.h in their scalar form, compiled for the
+    host, against a double-precision DFT — the folded -j, the sqrt(1/2) twiddles carried in the consuming FMA, the Hann window folded
+    into the first butterflies, and the pruned last level (bit-identical to the full transform on the outputs it forms)."""
+    exe = os.path.join(HARNESS, "butterfly_unit")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HARNESS, exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "butterfly_unit: ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_ring_and_engine_under_address_and_ub_sanitizers(built):
     """The same two programs built with -fsanitize=address,undefined (they cannot share a build with ThreadSanitizer): the pinned
     buffers' slot arithmetic, the carry-over copies of open epochs, the byte-sized layout of the wire-format ring."""

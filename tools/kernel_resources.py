@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Registers / scratch / occupancy of every sense_kernel instantiation, from hipcc's -Rpass-analysis=kernel-resource-usage remarks
+(csrc/build/resource_usage.txt, written by `make -C cognitive-radio-network_amd/csrc asm`)."""
+import re
+import subprocess
+import sys
+
+path = sys.argv[1] if len(sys.argv) > 1 else "cognitive-radio-network_amd/csrc/build/resource_usage.txt"
+txt = open(path).read()
+FLAGS = {2: 'Pair', 4: 'Spread', 32: 'LdsBlk', 64: 'Tw1C', 128: 'Fence', 256: 'Rows', 512: 'Multi', 1024: 'Prio', 2048: 'NoClose',
+         4096: 'Trace', 8192: 'RegB', 16384: 'HannSym', 32768: 'Tw2E', 65536: 'Aligned', 131072: 'Sc16'}
+K_V, K_S, K_X, K_O = "VGPRs", "SGPRs", r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
+bad = 0
+for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
+    name = b.split('\n')[0].strip().split(' ')[0]
+    if 'sense_kernel' not in name:
+        continue
+    def g(k):
+        m = re.search(k + r": (\d+)", b)
+        return m.group(1) if m else '?'
+    dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
+    a = [x.strip() for x in re.search(r"Cfg<(.*?)> ?>", dem).group(1).split(',')]
+    opt = int(a[-1])
+    fl = '|'.join(v for k, v in FLAGS.items() if opt & k)
+    v, s_, x, o = g(K_V), g(K_S), g(K_X), g(K_O)
+    want_occ = int(a[7])
+    flag = "" if (x == '0' and int(o) >= want_occ) else "   <-- scratch or occupancy below the launch bound"
+    bad += bool(flag)
+    print(f"R3={a[0]:>2} MAG={a[4][0]} WIN={a[5][0]} TW2LDS={a[6][0]} OCC={a[7]} ABL={a[8]} FULL={a[9][0]} {fl:48s} VGPR {v:>3} SGPR {s_:>3} scratch {x:>3} occ {o}{flag}")
+print(f"{bad} kernels with scratch or short of their occupancy")
