@@ -480,13 +480,27 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     const int groups = 256 / (c.fft_len / 16);
     const int64_t n_groups = (n_epochs + groups - 1) / groups;
     int64_t epw = n_groups / 2048;
-    p.groups_per_wg = (int)(epw < 1 ? 1 : epw > 4 ? 4 : epw);
-    if (h->groups_per_wg > 0) p.groups_per_wg = h->groups_per_wg;
-    // the last `tail` groups go to single-group workgroups (dispatched last): a short drain
-    int64_t tail = h->tail_groups >= 0 ? h->tail_groups : 1024;  // one per workgroup slot (256 CUs x 4): +0.9 % at N = 4096
+    epw = epw < 1 ? 1 : epw > 4 ? 4 : epw;
+    // the last `tail` groups go to short workgroups (dispatched last): a short drain
+    int64_t tail = 1024;        // one single-group workgroup per workgroup slot (256 CUs x 4): +0.9 % at N = 4096
+    int64_t tail_epw = 1;
+    // The Welch stream (windowed, hop = N/2, dense epochs) reads one half-frame twice per workgroup span — a span's first
+    // half-frame is the previous span's last — so its spans are made long: ~256 frames per big workgroup while at least ~2.7
+    // rounds of them remain over the 768 slots (3 workgroups per CU), a quarter of that per tail workgroup, one tail
+    // workgroup per slot.  At K = 8 that is 32 epochs / 8 epochs / 6144 epochs: traffic 1.005 x the algorithmic bytes instead
+    // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r03_welch_spans.txt).
+    if (c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop) {
+      const int64_t slots = 768;
+      epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups / 2048);
+      epw = epw < 1 ? 1 : epw > 64 ? 64 : epw;
+      tail_epw = epw / 4 < 1 ? 1 : epw / 4 > 8 ? 8 : epw / 4;
+      tail = slots * tail_epw;
+    }
+    p.groups_per_wg = (int)(h->groups_per_wg > 0 ? h->groups_per_wg : epw);
+    if (h->tail_groups >= 0) tail = h->tail_groups;
     if (tail > n_groups / 4) tail = n_groups / 4;
     p.n_big_wgs = (n_groups - tail) / p.groups_per_wg;
-    p.tail_groups_per_wg = h->tail_groups_per_wg > 0 ? h->tail_groups_per_wg : 1;
+    p.tail_groups_per_wg = (int)(h->tail_groups_per_wg > 0 ? h->tail_groups_per_wg : tail_epw);
   }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;
