@@ -54,11 +54,11 @@ def test_spectrum_monitor_tool_matches_float64(built, tmp_path, kind, fft, frame
     got = np.load(out)
     water, avg = _reference(x, fft, frames, alpha, kind)
     assert got["waterfall_db"].shape == (n_rows, fft)
-    # bins well above the fp32 noise of the transform (a single fp32 frame leaves ~1e-7 of the peak AMPLITUDE on every bin: 3e-3 of a
-    # bin 90 dB down, 1e-3 of one 80 dB down): 2e-3 dB within 80 dB of the peak, 1e-2 dB within 90 dB; every bin: 0.1 dB
-    strong, deep = water > water.max() - 80, water > water.max() - 90
-    assert np.abs(got["waterfall_db"] - water)[strong].max() < 2e-3 and np.abs(got["waterfall_db"] - water)[deep].max() < 1e-2
-    assert np.abs(got["average_db"] - avg)[strong].max() < 2e-3 and np.abs(got["average_db"] - avg)[deep].max() < 1e-2
+    # A single fp32 frame leaves ~1e-7 of the peak AMPLITUDE on every bin: 1e-4 of a bin 60 dB down (9e-4 dB), 3e-3 of one 90 dB down
+    # (0.03 dB).  Held: 2e-3 dB within 60 dB of the peak, 3e-2 dB within 90 dB, 0.1 dB on every bin.
+    strong, deep = water > water.max() - 60, water > water.max() - 90
+    assert np.abs(got["waterfall_db"] - water)[strong].max() < 2e-3 and np.abs(got["waterfall_db"] - water)[deep].max() < 3e-2
+    assert np.abs(got["average_db"] - avg)[strong].max() < 2e-3 and np.abs(got["average_db"] - avg)[deep].max() < 3e-2
     assert np.abs(got["waterfall_db"] - water).max() < 0.1 and np.abs(got["average_db"] - avg).max() < 0.1
     # what the display shows: the carrier that appears half way rises with the IIR's time constant
     col = fft // 2 - 200
