@@ -282,7 +282,9 @@ def main():
         workload += " [A/B BUILD libcrnsense_ab.so: measurement variant, not the shipped library]"
     pruned = "PASS3_ROWS" in info["name"]
     if pruned:
-        workload += " [kernel specialised to the reference channel plan's 7 of 16 output rows; config.alt.unpruned = any other plan]"
+        n_kept = info["name"].split("PASS3_ROWS=")[1].split("-of-16")[0]
+        workload += (f" [kernel specialised to the reference channel plan: pass 3 and the accumulate keep {n_kept} of 16 outputs per thread; "
+                     "--variant 2 / config.alt.unpruned = what any other plan runs]")
 
     iq = torch.zeros(n_samples * 2, dtype=torch.float32, device=dev)
     truth = torch.empty(E, dtype=torch.int32, device=dev)

@@ -37,7 +37,7 @@ struct crn_handle {
   int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
-  unsigned row_mask = 0xFFFFu;  // pass-3 output rows (256-bin blocks) any band touches, N = 4096
+  unsigned acc_mask = 0xFFFFu;  // accumulator registers (bit j R3 + d) that hold a bin of some band (N = 4096: the 256-bin rows)
   // one device slab holding every table
   void *d_tables = nullptr;
   const float2 *d_tw1 = nullptr, *d_tw2 = nullptr;
@@ -111,7 +111,7 @@ static int build_tables(crn_handle *h) {
   const crn_cfg &cfg = h->cfg;
   h->window_power = 0.0;
   h->aligned_shift = 0;
-  h->row_mask = 0xFFFFu;
+  h->acc_mask = 0xFFFFu;
   const int N = cfg.fft_len, R3 = N / 256, T = N / 16;
   std::vector<float2> tw1((size_t)17 * T), tw2((size_t)16 * R3);  // row 16 of tw1: W_N^{16 t}
   for (int i = 0; i < 16; i++)
@@ -143,10 +143,12 @@ static int build_tables(crn_handle *h) {
         for (int k = cfg.segs[s].lo; k < cfg.segs[s].hi; k++) bins.push_back(k);
       }
   }
-  if (N == 4096) {
-    h->row_mask = 0;
+  {
+    // bin k sits in register j R3 + d of its thread: d = k / 256, j = ((k % 256) / 16) mod J (crn_frame.h, pass 3)
+    const int J = 16 / R3;
+    h->acc_mask = 0;
     for (int sgi = 0; sgi < cfg.n_segs; sgi++)
-      for (int k = cfg.segs[sgi].lo; k < cfg.segs[sgi].hi; k++) h->row_mask |= 1u << (k >> 8);
+      for (int k = cfg.segs[sgi].lo; k < cfg.segs[sgi].hi; k++) h->acc_mask |= 1u << ((((k & 255) >> 4) % J) * R3 + (k >> 8));
   }
   if (N == 4096 && cfg.n_segs == cfg.n_bands && N % cfg.n_bands == 0 && cfg.decide != CRN_DECIDE_ANN) {
     const int W = N / cfg.n_bands;
@@ -363,20 +365,26 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
     bool reg_close = h->n_row_entries > 0 && h->cfg.window == CRN_WINDOW_RECT;
     if (plain4096) {  // of the A/B set only these carry the register form
       const int v = h->variant == 0 ? 13 : h->variant;
-      const bool rows_ok = (h->row_mask & ~0x8267u) == 0;
-      reg_close = reg_close && (v == 2 || v == 13 || v == 16 || v == 17 || v == 18 || (v == 7 && rows_ok));
+      const bool rows_ok = (h->acc_mask & ~0x8267u) == 0;
+      reg_close = reg_close && (v == 2 || v == 13 || v == 23 || v == 16 || v == 17 || v == 18 || (v == 7 && rows_ok));
     }
-    const bool pruned = plain4096 && reg_close && (h->variant == 0 || h->variant == 13) && (h->row_mask & ~0x8267u) == 0;
+    // pass 3 / accumulate pruned to the reference channel plan's registers: the plain 4096-point kernel's default form, and the
+    // register-close kernels of every other size and mode (what a launch without a spectrum output runs)
+    const unsigned ref_mask = crn::sense_ref_acc_mask(h->cfg.fft_len);
+    const bool inside = (h->acc_mask & ~ref_mask) == 0 && ref_mask != 0xFFFFu && h->variant != 2;
+    const bool pruned = reg_close && inside && h->cfg.window == CRN_WINDOW_RECT && (!plain4096 || h->variant == 0 || h->variant == 13 || h->variant == 23);
     // periodic Hann in energy mode: the window is folded into pass 1 (whole frames); with the Welch scan's plan
     // (N = 4096, equal contiguous bands) the close forms band sums by DPP
     const bool hann_fold = h->cfg.window == CRN_WINDOW_HANN && h->cfg.mode != CRN_MODE_REF_MAG;
     const bool aligned = hann_fold && h->cfg.fft_len == 4096 && h->aligned_shift != 0;
     if (hann_fold) tl = 1;
+    char prune_note[64] = "";
+    if (pruned) std::snprintf(prune_note, sizeof(prune_note), ",PASS3_ROWS=%d-of-16(reference channel plan)", __builtin_popcount(ref_mask));
     std::snprintf(name, (size_t)name_len, "sense_kernel<R3=%d,NBUF=%d,PREFETCH=%d,NT=%d,TW2LDS=%d,PK=%d,MAG=%d,WIN=%s,CLOSE=%s%s>",
                   h->cfg.fft_len / 256, nbuf, pf, nt, tl, pk,
                   h->cfg.mode == CRN_MODE_REF_MAG, h->cfg.window == CRN_WINDOW_RECT ? "0" : hann_fold ? "hann-in-pass1" : "table",
                   aligned ? "aligned-bands(dpp)" : reg_close ? "registers" : "lds",
-                  pruned ? ",PASS3_ROWS=0x8267(reference channel plan; full rows when a spectrum is requested)" : "");
+                  prune_note);
   }
   return CRN_OK;
 }
@@ -518,7 +526,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   p.ref_band = c.ref_band;
   p.hann_sym = c.window == CRN_WINDOW_HANN;
   p.aligned_shift = d_out->spectrum == nullptr ? h->aligned_shift : 0;
-  p.row_mask = h->row_mask;
+  p.acc_mask = h->variant == 2 ? 0xFFFFu : h->acc_mask;   // variant 2: no pruning at any size
   {  // 1 / full scale for a sum of magnitudes, its square for energies (2^-15 / 2^-30 by default: exact)
     const double u = 1.0 / h->wire_full_scale;
     p.wire_unscale = (float)(c.mode == CRN_MODE_REF_MAG ? u : u * u);

@@ -268,6 +268,20 @@ CRN_HD void dft16_hann(const cx (&in)[16], cx (&out)[16], const cx (&wp)[4], con
 // for, pass 3 forms and accumulates only the needed outputs (bit-identical for those bins).
 static constexpr unsigned kRefPlanRows = 0x8267u;  // rows {0, 1, 2, 5, 6, 9, 15}
 
+// The same at every size.  After pass 3 thread (a, g) holds bin a + 16 (g J + j) + 256 d in accumulator register j R3 + d
+// (J = 16 / R3, N = 256 R3): which of the 16 registers can hold a bin of the reference's channel plan scaled to N points — bit
+// j R3 + d.  N = 4096: the rows above (J = 1: register = row), 7 of 16; N = 512: 7; N = 1024: 12; N = 2048: 11.  Band tables inside
+// the mask, with no per-bin spectrum asked for, run kernels whose pass 3 forms and accumulates only those registers.
+constexpr unsigned ref_acc_mask(int R3) {
+  const int seg[5][2] = {{0, 16}, {496, 511}, {55, 85}, {189, 222}, {300, 310}};   // CE_Predictive_Node.cpp:173-191, of 512 bins
+  const int J = 16 / R3, S = R3 / 2;                                               // N / 512
+  unsigned mask = 0;
+  for (int s = 0; s < 5; s++)
+    for (int k = seg[s][0] * S; k < seg[s][1] * S; k++) mask |= 1u << ((((k & 255) >> 4) % J) * R3 + (k >> 8));
+  return mask;
+}
+static_assert(ref_acc_mask(16) == kRefPlanRows, "N = 4096: register = 256-bin row");
+
 // DFT16 whose last level only forms the outputs named in MASK (bit d = X[d] needed).
 template <bool PK, unsigned MASK>
 CRN_HD void dft16_pruned(const cx (&in)[16], cx (&out)[16]) {
@@ -316,6 +330,46 @@ CRN_HD void dft16_pruned(const cx (&in)[16], cx (&out)[16]) {
       }
     }
   });
+}
+
+// 4-point transform that forms only the outputs named in MSK (bit k = a_k needed); the ones it forms are dft4's, bit for bit.
+template <bool PK, unsigned MSK, bool B2MJ = false>
+CRN_HD void dft4_pruned(cx &a0, cx &a1, cx &a2, cx &a3) {
+  using m = M<PK>;
+  constexpr bool S = (MSK & 5u) != 0, D = (MSK & 10u) != 0;   // outputs 0 / 2 need the sums, 1 / 3 the differences
+  cx s02 = a0, d02 = a0, s13 = a1, d13 = a1;
+  if constexpr (S) { s02 = B2MJ ? m::add_mj(a0, a2) : m::add(a0, a2); s13 = m::add(a1, a3); }
+  if constexpr (D) { d02 = B2MJ ? m::sub_mj(a0, a2) : m::sub(a0, a2); d13 = m::sub(a1, a3); }
+  if constexpr ((MSK & 1u) != 0) a0 = m::add(s02, s13);
+  if constexpr ((MSK & 4u) != 0) a2 = m::sub(s02, s13);
+  if constexpr ((MSK & 2u) != 0) a1 = m::add_mj(d02, d13);
+  if constexpr ((MSK & 8u) != 0) a3 = m::sub_mj(d02, d13);
+}
+
+// 8-point transform that forms only the outputs named in M8 (bit d); same operations as dft8 for those.
+template <bool PK, unsigned M8>
+CRN_HD void dft8_pruned(const cx (&in)[8], cx (&out)[8]) {
+  using m = M<PK>;
+  cx y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) y[i] = in[i];
+  constexpr unsigned need = (M8 | (M8 >> 4)) & 15u;   // E[a0] and O[a0] are needed when output a0 or a0 + 4 is
+  dft4_pruned<PK, need>(y[0], y[2], y[4], y[6]);
+  dft4_pruned<PK, need>(y[1], y[3], y[5], y[7]);
+  if constexpr ((M8 & 0x01u) != 0) out[0] = m::add(y[0], y[1]);
+  if constexpr ((M8 & 0x10u) != 0) out[4] = m::sub(y[0], y[1]);
+  if constexpr ((M8 & 0x22u) != 0) {
+    const cx p = m::add_mj(y[3], y[3]);
+    if constexpr ((M8 & 0x02u) != 0) out[1] = m::fma_h(p, y[2]);
+    if constexpr ((M8 & 0x20u) != 0) out[5] = m::fms_h(p, y[2]);
+  }
+  if constexpr ((M8 & 0x04u) != 0) out[2] = m::add_mj(y[4], y[5]);
+  if constexpr ((M8 & 0x40u) != 0) out[6] = m::sub_mj(y[4], y[5]);
+  if constexpr ((M8 & 0x88u) != 0) {
+    const cx q = m::sub_mj(y[7], y[7]);
+    if constexpr ((M8 & 0x08u) != 0) out[3] = m::fms_h(q, y[6]);
+    if constexpr ((M8 & 0x80u) != 0) out[7] = m::fma_h(q, y[6]);
+  }
 }
 
 // 8-point forward DFT as 2 x 4.

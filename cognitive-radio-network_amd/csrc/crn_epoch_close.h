@@ -281,8 +281,11 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     // traffic of the CU's other waves: measured ~500 ticks each): the entries come through the
     // scalar cache, the features stay in lanes, the thresholds are fetched first and used last.
     constexpr int CAP = kRowEntryWords / R3;  // entry slots per row
-    constexpr auto row_live = [](int d) {
-      return !((C::OPT & kRows) != 0 && R3 == 16 && !MAG) || ((kRefPlanRows >> d) & 1) != 0;
+    constexpr unsigned AM = acc_mask<C>();   // registers j R3 + d the kernel keeps (all of them unless kRows)
+    constexpr auto row_live = [](int d) {     // some register of row d is kept
+      for (int j = 0; j < J; j++)
+        if ((acc_mask<C>() >> (j * R3 + d)) & 1u) return true;
+      return false;
     };
     float thr_lane = 0.f;
     if constexpr (TPG == 1) thr_lane = thr[lane & 15];  // fetched first, used last
@@ -290,7 +293,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     // costs SGPRs the frame loop needs (the spill lanes' VGPR pushed a loop address to scratch)
     constexpr auto next_live = [](int d) {
       for (int x = d + 1; x < R3; x++)
-        if (!((C::OPT & kRows) != 0 && R3 == 16 && !MAG) || ((kRefPlanRows >> x) & 1) != 0) return x;
+        for (int j = 0; j < J; j++)
+          if ((acc_mask<C>() >> (j * R3 + x)) & 1u) return x;
       return (int)R3;
     };
     constexpr int kFirst = next_live(-1);
@@ -311,6 +315,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < J; j++) {
+              if (((AM >> (j * R3 + d)) & 1u) == 0) continue;   // never accumulated: no band of the plan reaches it
               const int base = a + 16 * (m_lo * J + j);
               v += (unsigned)(base - lo) < (unsigned)span ? acc[j * R3 + d] : 0.f;
             }
@@ -382,10 +387,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     for (int j = 0; j < J; j++)
 #pragma unroll
       for (int d = 0; d < R3; d++) {
-        // the row-pruned kernel never accumulates (or reads back) the other rows
-        if constexpr ((C::OPT & kRows) != 0 && R3 == 16 && !MAG) {
-          if (!((kRefPlanRows >> d) & 1)) continue;
-        }
+        // the pruned kernels never accumulate (or read back) the other registers
+        if (((acc_mask<C>() >> (j * R3 + d)) & 1u) == 0) continue;
         const int k = a + 16 * (m_lo * J + j) + 256 * d;
         spec[spec_phys(k)] = acc[j * R3 + d];
       }

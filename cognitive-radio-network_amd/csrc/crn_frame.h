@@ -123,7 +123,7 @@ enum : int {
   kLdsBlk = 32,  // LDS reads as hand-written ds_read_b64 blocks (no ds_read2_b64 merging)
   kTw1C = 64,    // pass-1 twiddles stored compressed (9 instead of 15 complex values)
   kFence = 128,  // sched_barrier after pass 1
-  kRows = 256,   // pass 3 limited to the reference channel plan's output rows
+  kRows = 256,   // pass 3 and the accumulate limited to the registers that can hold a bin of the reference channel plan (ref_acc_mask)
   kMulti = 512,  // a workgroup streams through several consecutive epoch groups
   kPrioValu = 1024, // s_setprio 1 through the butterflies of passes 1 and 2 (where the prefetch loads issue)
   kNoClose = 2048,  // A/B build only, measurement ablation: the epoch close only folds and resets the accumulators
@@ -378,13 +378,67 @@ CRN_DEV void ph_pass3(cx (&u)[16], cx (&v)[16]) {
   }
 }
 
+// Accumulator registers a kernel keeps: all 16, or (kRows) those that can hold a bin of the reference channel plan.
+template <class C>
+constexpr unsigned acc_mask() {
+  return (C::OPT & kRows) != 0 ? ref_acc_mask(C::R3) : 0xFFFFu;
+}
+
+// pass 3 restricted to the outputs named in MASK (bit j R3 + d); what it forms is what ph_pass3 forms, bit for bit
+template <class C, unsigned MASK>
+CRN_DEV void ph_pass3_pruned(cx (&u)[16], cx (&v)[16]) {
+  constexpr int R3 = C::R3, J = Geo<R3>::J;
+  using m = M<C::PK>;
+  if constexpr (R3 == 16) {
+    dft16_pruned<C::PK, MASK>(u, v);
+  } else if constexpr (R3 == 8) {
+    static_for<J>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr unsigned M8 = (MASK >> (j * 8)) & 0xFFu;
+      if constexpr (M8 != 0) {
+        cx in8[8], out8[8];
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++) in8[mm] = u[j * 8 + mm];
+        dft8_pruned<C::PK, M8>(in8, out8);
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++)
+          if ((M8 >> mm) & 1) v[j * 8 + mm] = out8[mm];
+      }
+    });
+  } else if constexpr (R3 == 4) {
+    static_for<J>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr unsigned M4 = (MASK >> (j * 4)) & 0xFu;
+      if constexpr (M4 != 0) {
+        dft4_pruned<C::PK, M4>(u[j * 4], u[j * 4 + 1], u[j * 4 + 2], u[j * 4 + 3]);
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) v[j * 4 + mm] = u[j * 4 + mm];
+      }
+    });
+  } else {
+    static_for<J>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (((MASK >> (j * 2)) & 1u) != 0) v[j * 2] = m::add(u[j * 2], u[j * 2 + 1]);
+      if constexpr (((MASK >> (j * 2 + 1)) & 1u) != 0) v[j * 2 + 1] = m::sub(u[j * 2], u[j * 2 + 1]);
+    });
+  }
+}
+
 // pass 3 + per-bin accumulate: v[j * R3 + d] is bin a + 16 (m_lo J + j) + 256 d
 template <class C>
 CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
   cx v[16];
-  ph_pass3<C>(u, v);
+  constexpr unsigned MASK = acc_mask<C>();
+  if constexpr (MASK == 0xFFFFu) {
+    ph_pass3<C>(u, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = cx{0.f, 0.f};
+    ph_pass3_pruned<C, MASK>(u, v);
+  }
 #pragma unroll
   for (int i = 0; i < 16; i++) {
+    if (((MASK >> i) & 1u) == 0) continue;   // a register no band of the plan reaches: neither formed nor accumulated
     if constexpr (C::MAG) {
       // |X| / K per frame.  v_sqrt_f32 (1 ulp) and a multiply by 1/K instead of the reference's
       // correctly rounded hypotf and divide: each addend moves by <= 2 ulp, five orders of
@@ -434,16 +488,6 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
     ph_x2_write<C>(v, buf, c);
     wave_sync();
     ph_x2_read<C>(u, buf, c);
-    if constexpr ((C::OPT & kRows) != 0 && C::R3 == 16 && !C::MAG) {
-      constexpr unsigned MASK = kRefPlanRows;
-#pragma unroll
-      for (int i = 0; i < 16; i++) v[i] = cx{0.f, 0.f};
-      dft16_pruned<C::PK, MASK>(u, v);
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        if ((MASK >> i) & 1) c.acc[i] = fmaf(v[i].y, v[i].y, fmaf(v[i].x, v[i].x, c.acc[i]));
-      return;
-    }
     ph_pass3_acc<C>(u, c);
     return;
   }

@@ -47,7 +47,8 @@ struct SenseParams {
   int n_row_entries;       // > 0: band sums from registers (epoch_close); entries in band_tab
   int aligned_shift;       // N = 4096 and the plan is n_bands equal contiguous bands of 2^aligned_shift bins (6..8), else 0
   int hann_sym;            // the window table is a periodic Hann: w[n + N/2] = 1 - w[n] (may be folded into pass 1)
-  unsigned row_mask;       // N = 4096: bit d set when some band touches bins [256 d, 256 d + 256)
+  unsigned acc_mask;       // bit j R3 + d set when some band holds a bin of the form a + 16 (g J + j) + 256 d, i.e. when accumulator
+                           // register j R3 + d of some thread holds a band bin (N = 4096: bit d = the 256-bin row d)
   float wire_unscale;      // wire-format launches: 1 / full scale (2^-15 by default) for a sum of magnitudes, its square for energies
   // outputs (device, nullable)
   float *features;
@@ -82,6 +83,7 @@ struct SynthParams {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream, bool sc16 = false);
 int sense_num_variants();
+unsigned sense_ref_acc_mask(int fft_len);    // accumulator registers (bit j R3 + d) the reference channel plan reaches at this size
 bool sense_variant_available(int variant);   // the shipped library carries 0 (= 13), 2 and 23; libcrnsense_ab.so all of them
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);

@@ -120,7 +120,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
       case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, kPair>(p, mag, win, stream);
       case 7:
-        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kMulti>(p, mag, win, stream);
       case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
@@ -131,7 +131,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
 #endif
       case 13:
         // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
-        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         if (reg_bands(p))
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
@@ -144,7 +144,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
 #endif
       case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
-        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kPrioValu | kMulti>(p, mag, win, stream);
     }
@@ -165,6 +165,7 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 }
 
 int sense_num_variants() { return kNumVariants; }
+unsigned sense_ref_acc_mask(int fft_len) { return ref_acc_mask(fft_len / 256); }
 
 // Does this build of the library carry variant v?  (0 = default.)
 bool sense_variant_available(int v) {

@@ -11,7 +11,7 @@ static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int va
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
   if (win) {
     // everything that is not the Welch configuration's kernel: the generic windowed kernels (window table in registers)
-    if (mag || !p.hann_sym || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2>(p, mag, win, stream);
+    if (mag || !p.hann_sym || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2, false>(p, mag, win, stream);
     if constexpr (R3 == 16) {
       if (p.aligned_shift != 0)
         return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);
@@ -21,17 +21,17 @@ static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int va
   if constexpr (R3 == 16) {
     if (!mag && p.L == Geo<R3>::N) {
       if (variant == 23) {  // A/B: every twiddle in registers, 3 workgroups per CU (the float path's variant 23)
-        if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, false, 3, 0, true, kBase | kRows | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, false, 3, 0, true, kBase>(p, mag, win, stream);
       }
-      if (reg_bands(p) && (p.row_mask & ~kRefPlanRows) == 0)
+      if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRows | kRegBands>(p, mag, win, stream);
       if (reg_bands(p)) return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C | kRegBands>(p, mag, win, stream);
       return launch_rn<R3, 1, true, true, true, 4, 0, true, kBase | kTw1C>(p, mag, win, stream);
     }
   }
-  return launch_default<R3, 1, true, true, false, 3, true, kBase, 1>(p, mag, win, stream);
+  return launch_default<R3, 1, true, true, false, 3, true, kBase, 1, false>(p, mag, win, stream);   // (no plan-specific pruning in wire format)
 }
 
 hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream) {

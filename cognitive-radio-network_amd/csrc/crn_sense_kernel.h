@@ -350,15 +350,28 @@ static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.sp
 
 // Default configuration of every size: all mode / window / short-frame combinations.
 template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti,
-          int WHICH = 0 /* 0 all, 1 unwindowed kernels only, 2 windowed only */>
+          int WHICH = 0 /* 0 all, 1 unwindowed kernels only, 2 windowed only */, bool PRUNE = true>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
   const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
+  // ... and when every band bin sits in a register the reference channel plan also uses (ref_acc_mask), pass 3 and the accumulate
+  // keep only those registers: 7 of 16 at N = 512 (where the reference's |X| costs a square root per bin and frame), 12 / 11 / 7 at
+  // 1024 / 2048 / 4096
+  [[maybe_unused]] const bool prune = PRUNE && regb && ref_acc_mask(R3) != 0xFFFFu && (p.acc_mask & ~ref_acc_mask(R3)) == 0;
 #define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
 #define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
   if constexpr (WHICH != 1) {
     if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
     if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
+  }
+  if constexpr (WHICH != 2 && PRUNE) {
+#define CRN_GO_RP(MAGV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, false, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands | kRows>>(p, stream)
+    if (prune) {
+      if (mag) { if (full) CRN_GO_RP(true, true); else CRN_GO_RP(true, false); }
+      if (full) CRN_GO_RP(false, true);
+      CRN_GO_RP(false, false);
+    }
+#undef CRN_GO_RP
   }
   if constexpr (WHICH != 2) {
     if (regb) {

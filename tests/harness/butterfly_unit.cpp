@@ -68,6 +68,29 @@ int main() {
       dft(x, X, 8);
       check("dft8", o8, X, 8);
     }
+    {
+      // the pruned 4- and 8-point forms: whatever subset of outputs they are asked for is the full transform's, bit for bit
+      cx f4[4] = {in[0], in[1], in[2], in[3]};
+      crn::dft4<false>(f4[0], f4[1], f4[2], f4[3]);
+      cx f8[8], i8[8];
+      for (int i = 0; i < 8; i++) i8[i] = in[i];
+      crn::dft8<false>(i8, f8);
+      crn::static_for<15>([&](auto mc) {
+        constexpr unsigned M4 = decltype(mc)::value + 1;
+        cx p4[4] = {in[0], in[1], in[2], in[3]};
+        crn::dft4_pruned<false, M4>(p4[0], p4[1], p4[2], p4[3]);
+        for (int k = 0; k < 4; k++)
+          if (((M4 >> k) & 1) && (p4[k].x != f4[k].x || p4[k].y != f4[k].y)) { fprintf(stderr, "butterfly_unit: dft4_pruned<%u> output %d\n", M4, k); exit(1); }
+      });
+      crn::static_for<255>([&](auto mc) {
+        constexpr unsigned M8 = decltype(mc)::value + 1;
+        cx p8[8];
+        for (int i = 0; i < 8; i++) p8[i] = cx{0.f, 0.f};
+        crn::dft8_pruned<false, M8>(i8, p8);
+        for (int k = 0; k < 8; k++)
+          if (((M8 >> k) & 1) && (p8[k].x != f8[k].x || p8[k].y != f8[k].y)) { fprintf(stderr, "butterfly_unit: dft8_pruned<%u> output %d\n", M8, k); exit(1); }
+      });
+    }
     crn::dft16<false>(in, out);
     dft(x, X, 16);
     check("dft16", out, X, 16);
@@ -99,6 +122,23 @@ int main() {
       dft(xw, X, 16);
       check("dft16_hann", ho, X, 16);
     }
+  }
+  // which accumulator registers the reference channel plan reaches, per size (csrc/crn_butterflies.h: ref_acc_mask): restated here from
+  // the bin ranges of CE_Predictive_Node.cpp:173-191 by walking every thread's bins
+  for (int R3 : {2, 4, 8, 16}) {
+    const int N = 256 * R3, J = 16 / R3, S = N / 512;
+    const int seg[5][2] = {{0, 16}, {496, 511}, {55, 85}, {189, 222}, {300, 310}};
+    unsigned mask = 0;
+    for (int a = 0; a < 16; a++)
+      for (int g = 0; g < R3; g++)
+        for (int j = 0; j < J; j++)
+          for (int d = 0; d < R3; d++) {
+            const int k = a + 16 * (g * J + j) + 256 * d;   // the bin thread (a, g) holds in register j R3 + d
+            for (int sgi = 0; sgi < 5; sgi++)
+              if (k >= seg[sgi][0] * S && k < seg[sgi][1] * S) mask |= 1u << (j * R3 + d);
+          }
+    if (mask != crn::ref_acc_mask(R3)) { fprintf(stderr, "butterfly_unit: ref_acc_mask(%d) = %#x, walking the bins gives %#x\n", R3, crn::ref_acc_mask(R3), mask); return 1; }
+    printf("butterfly_unit: N = %4d: the reference channel plan reaches %2d of 16 accumulator registers (mask %#06x)\n", N, __builtin_popcount(mask), mask);
   }
   printf("butterfly_unit: ok (worst error %.3g of the largest output)\n", worst);
   return 0;

@@ -363,6 +363,49 @@ def test_shipped_library_carries_no_measurement_variants(built):
     s.close()
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+@pytest.mark.parametrize("mode", ["energy", "mag"])
+def test_plan_pruned_kernels_equal_the_full_ones(built, n, mode):
+    """With the reference channel plan (at any size) and no spectrum output the launch runs kernels whose pass 3 and accumulate keep
+    only the registers that plan reaches (7 / 12 / 11 / 7 of 16 at N = 512 / 1024 / 2048 / 4096); variant 2 runs the full kernels.
+    Same operations on the kept bins: features, network outputs, decisions and occupancy are bit-identical — whole frames and the
+    radio's 364-sample packets; and a band table that reaches other registers silently gets the full kernel (checked against the
+    oracle)."""
+    cfg = cs.cfg_energy_scaled(n, 4.0) if mode == "energy" else cs.cfg_reference_scaled(n)
+    n_epochs = 37
+    for L in (n, 364):
+        iq, _ = signals.make_epochs(cfg, n_epochs, seed=3 * n + L, L=L)
+        res = []
+        for v in (0, 2):
+            s = cs.Sensor(cfg)
+            s.set_variant(v)
+            name = s.kernel_info()["name"]
+            assert ("PASS3_ROWS" in name) == (v == 0), name
+            res.append(s.run_host(iq, n_epochs, L=L))
+            s.close()
+        for k in ("features", "ann_out", "decision", "occupancy"):
+            assert np.array_equal(res[0][k], res[1][k]), (k, L)
+        want = orc.run(cfg, iq, n_epochs, L=L)
+        assert (np.abs(res[0]["features"] - want["features"]) / np.abs(want["features"])).max() < FEATURE_TOL
+        assert np.array_equal(res[0]["decision"], want["decision"])
+    # one more band bin, in a register the plan does not reach: no pruned kernel for this handle
+    other = cs.cfg_energy_scaled(n, 4.0)
+    taken = {k for sg in range(other.n_segs) for k in range(other.segs[sg].lo, other.segs[sg].hi)}
+    ref_bits = 0
+    r3, j_per = n // 256, 16 // (n // 256)
+    for k in taken:
+        ref_bits |= 1 << ((((k & 255) >> 4) % j_per) * r3 + (k >> 8))
+    extra = next(k for k in range(n) if not (ref_bits >> ((((k & 255) >> 4) % j_per) * r3 + (k >> 8))) & 1)
+    other.segs[other.n_segs].lo, other.segs[other.n_segs].hi, other.segs[other.n_segs].band = extra, extra + 1, 3
+    other.n_segs += 1
+    s = cs.Sensor(other)
+    assert "PASS3_ROWS" not in s.kernel_info()["name"]
+    iq, _ = signals.make_epochs(cfg, 8, seed=5)
+    got, want = s.run_host(iq, 8), orc.run(other, iq, 8)
+    s.close()
+    assert (np.abs(got["features"] - want["features"]) / np.abs(want["features"])).max() < FEATURE_TOL
+
+
 def test_power_of_two_scaling_is_exact(built):
     """Linearity property, size independent: x -> 2x multiplies every energy by exactly 4."""
     cfg = cs.cfg_energy_scaled(4096, 4.0)
