@@ -3,7 +3,7 @@
 profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(R, "gpurun_out", tag)
 DST = os.path.join(R, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -20,7 +20,14 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("per_bin_error_at_floor.txt", f"{tag}_per_bin_error_at_floor.txt"),
                  ("engine_execute_latency.txt", f"{tag}_engine_execute_latency.txt"),
                  ("bench_adc16.jsonl", f"{tag}_bench_radio_format_input.jsonl"),
-                 ("bench_wire_format.jsonl", f"{tag}_bench_wire_format_sc16.jsonl"), ("ring_rate.txt", f"{tag}_ring_rate_round.txt")):
+                 ("bench_wire_format.jsonl", f"{tag}_bench_wire_format_sc16.jsonl"), ("ring_rate.txt", f"{tag}_ring_rate_round.txt"),
+                 ("bench_v23.json", f"{tag}_bench_headline_all_twiddles_in_registers.json"),
+                 ("bench_driver_shape.json", f"{tag}_bench_driver_shape.json"),
+                 ("bench_8ranks_one_gpu.json", f"{tag}_bench_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
+                 ("bench_8ranks_one_gpu_scan.json", f"{tag}_bench_cfg4_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
+                 ("welch_spans.txt", f"{tag}_welch_spans.txt"), ("soak.txt", f"{tag}_soak.txt"),
+                 ("per_bin_error_vs_snr.txt", f"{tag}_per_bin_error_vs_snr.txt"),
+                 ("engine_between_ecr_threads.txt", f"{tag}_engine_between_ecr_threads.txt")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
         shutil.copy(m[-1], os.path.join(DST, dst))
@@ -46,7 +53,7 @@ out = {"_how": HOW}
 for key, sub, bench in (("energy4096", "_headline", "bench_headline.json"), ("energy1024", "_cfg1", "bench_cfg1_1024.json"),
                         ("ref512", "_cfg3", "bench_cfg3_ref512.json"), ("welch4096", "_cfg2", "bench_cfg2_welch.json"),
                         ("energy512", "_e512", "bench_e512.json"), ("energy2048", "_e2048", "bench_e2048.json"),
-                        ("energy4096_unpruned", "_unpruned", "bench_unpruned.json")):
+                        ("energy4096_unpruned", "_unpruned", "bench_unpruned.json"), ("welch4096_K32", "_cfg2K32", "bench_cfg2_welch_K32.json")):
     fetch, write = mean_counter("pmc_fetch" + sub, "FETCH_SIZE"), mean_counter("pmc_write" + sub, "WRITE_SIZE")
     bj = os.path.join(SRC, bench)
     if fetch is None or not os.path.exists(bj):
@@ -55,16 +62,21 @@ for key, sub, bench in (("energy4096", "_headline", "bench_headline.json"), ("en
         head = json.load(open(bj))
     except Exception:
         continue
+    algo = head["config"]["bytes_per_gpu_per_step"]
     out[key] = {"epochs": head["config"]["epochs_per_gpu"], "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                 "hbm_bytes_per_launch": int(fetch * 1024 * 2 + (write or 0) * 1024),
-                "algorithmic_bytes_per_launch": head["config"]["bytes_per_gpu_per_step"]}
+                "algorithmic_bytes_per_launch": algo,
+                # reads against the 8 B per unique input sample; everything (the per-epoch outputs are written once: features, occupancy,
+                # decision, network outputs — 0.01 % of the bytes for the 4-band plans, 0.25 % for the 64-band scan) against the same
+                "read_over_algorithmic": fetch * 1024 * 2 / algo,
+                "total_over_algorithmic": (fetch * 1024 * 2 + (write or 0) * 1024) / algo}
     print(key, out[key])
 if len(out) > 1:
     json.dump(out, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
 subprocess.run([sys.executable, os.path.join(R, "tools", "collect_valu_counters.py"), tag,
                 f"energy4096=pmc_{tag}_headline:", f"welch4096=pmc_{tag}_welch:--mode welch", f"energy2048=pmc_{tag}_e2048:--fft 2048",
-                f"ref512=pmc_{tag}_ref:--mode ref", f"energy1024=pmc_{tag}_e1024:--fft 1024"])
-for name in ("headline", "welch", "e2048", "ref", "e1024"):
+                f"ref512=pmc_{tag}_ref:--mode ref", f"energy1024=pmc_{tag}_e1024:--fft 1024", f"energy4096unpruned=pmc_{tag}_unpruned:--variant 2"])
+for name in ("headline", "welch", "e2048", "ref", "e1024", "unpruned"):
     src = os.path.join(SRC, f"pmc_sq_{name}.txt")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_pmc_sq_{name}.txt"))

@@ -3,7 +3,7 @@
 the evidence cannot drift apart.  usage: python tools/design_table.py [tag]"""
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def load(name):

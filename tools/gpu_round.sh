@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round evidence (tag $TAG, default r02): GPU tests, smoke, every bench line, rocprofv3 kernel stats of the headline
+# Round evidence (tag $TAG, default r03): GPU tests, smoke, every bench line, rocprofv3 kernel stats of the headline
 # command, HBM traffic counters (separate --pmc passes per workload), SQ / GRBM counter groups for the VALU-side
 # figures, the engine's execute() latency, host-buffer (PCIe-inclusive) rate, zero-input and power / clock probes.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -15,7 +15,16 @@ timeout 300 python bench.py --mode ref --cpu-epochs 0 > $O/bench_cfg3_ref512.jso
 timeout 300 python bench.py --mode welch --cpu-epochs 0 > $O/bench_cfg2_welch.json 2> $O/bench_cfg2.err
 timeout 300 python bench.py --mode welch --cpu-epochs 0 --frames 32 > $O/bench_cfg2_welch_K32.json 2> $O/bench_cfg2_K32.err
 timeout 300 python bench.py --mode scan --cpu-epochs 0 --force-collective > $O/bench_cfg4_scan_1rank.json 2> $O/bench_cfg4.err
-timeout 300 python bench.py --variant 16 --cpu-epochs 0 --no-check --no-alt > $O/bench_noclose.json 2> $O/bench_noclose.err
+timeout 300 python bench.py --variant 16 --cpu-epochs 0 --no-check --no-alt > $O/bench_noclose.json 2> $O/bench_noclose.err   # (A/B build: libcrnsense_ab.so)
+timeout 300 python bench.py --variant 2 --cpu-epochs 0 --no-alt > $O/bench_unpruned.json 2> $O/bench_unpruned.err
+timeout 300 python bench.py --variant 23 --cpu-epochs 0 --no-alt > $O/bench_v23.json 2> $O/bench_v23.err
+# the driver's command shape, and BASELINE.json configs[4] rehearsed the way the driver starts it: no launcher, bench.py starts its own
+# ranks; eight of them share this box's one GPU over the stand-in RCCL (real RCCL refuses two ranks per device)
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
+CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0 timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --epochs 3584 --cpu-epochs 0 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err
+CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0 timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --mode scan --epochs 8960 --cpu-epochs 0 > $O/bench_8ranks_one_gpu_scan.json 2> $O/bench_8ranks_one_gpu_scan.err
+timeout 900 python tools/gpu_welch_spans.py > $O/welch_spans.txt 2>&1
+timeout 900 python tests/soak_gpu.py 20000 > $O/soak.txt 2>&1
 timeout 300 python bench.py --fft 512 --cpu-epochs 0 > $O/bench_e512.json 2> $O/bench_e512.err
 timeout 300 python bench.py --fft 2048 --cpu-epochs 0 > $O/bench_e2048.json 2> $O/bench_e2048.err
 # the same kernels on samples rounded to the USRP's 16-bit wire format (what the reference's radios deliver): diagnostic lines
@@ -33,14 +42,14 @@ cd /tmp && export TMPDIR=/tmp
 PYTHON=$(python3 -c 'import os, sys; print(os.path.realpath(sys.executable))')   # the real binary: no launcher hop behind rocprofv3's `--`
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $PYTHON $R/bench.py --cpu-epochs 0 --no-live-traffic --no-alt > $O/stats.log 2>&1
 # HBM traffic per workload (FETCH_SIZE and WRITE_SIZE in separate passes)
-for cfgname in "headline:" "cfg1:--fft 1024" "cfg3:--mode ref" "cfg2:--mode welch" "e512:--fft 512" "e2048:--fft 2048" "unpruned:--variant 2"; do
+for cfgname in "headline:" "cfg1:--fft 1024" "cfg3:--mode ref" "cfg2:--mode welch" "e512:--fft 512" "e2048:--fft 2048" "unpruned:--variant 2" "cfg2K32:--mode welch --frames 32"; do
   tag=${cfgname%%:*}; args=${cfgname#*:}
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- $PYTHON $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_fetch_$tag.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- $PYTHON $R/bench.py --steps 5 --warmup 20 --cpu-epochs 0 --no-live-traffic --no-alt $args > $O/pmc_write_$tag.log 2>&1
 done
 cd $R
 # SQ / LDS / VMEM / GRBM counter groups per workload (tools/gpu_pmc.sh -> gpurun_out/pmc_<name>)
-for cfgname in "headline:" "welch:--mode welch" "e2048:--fft 2048" "ref:--mode ref" "e1024:--fft 1024"; do
+for cfgname in "headline:" "welch:--mode welch" "e2048:--fft 2048" "ref:--mode ref" "e1024:--fft 1024" "unpruned:--variant 2"; do
   tag=${cfgname%%:*}; args=${cfgname#*:}
   TAG=${TAG}_$tag EXTRA="--no-alt $args" bash tools/gpu_pmc.sh > $O/pmc_sq_$tag.txt 2>&1
 done
