@@ -37,6 +37,7 @@ struct crn_handle {
   int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
+  int n_cus = 256;              // compute units of cfg.device (workgroup slots = n_cus x workgroups per CU): read at creation
   unsigned acc_mask = 0xFFFFu;  // accumulator registers (bit j R3 + d) that hold a bin of some band (N = 4096: the 256-bin rows)
   // one device slab holding every table
   void *d_tables = nullptr;
@@ -295,6 +296,10 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   crn_handle *h = new (std::nothrow) crn_handle();
   if (!h) return crn::fail(CRN_ERR_NOMEM, "out of host memory");
   h->cfg = *cfg;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_cus = cus;
+  }
   if (int rc = build_tables(h)) {
     delete h;
     return rc;
@@ -487,10 +492,12 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // +0.5-1.5 % on 2048 .. 12288-epoch batches over the earlier n_groups / 4096).
     const int groups = 256 / (c.fft_len / 16);
     const int64_t n_groups = (n_epochs + groups - 1) / groups;
-    int64_t epw = n_groups / 2048;
+    // workgroup slots of this device: CUs x workgroups per CU (4 for the plain kernels' register budget, 3 for the windowed ones)
+    const int64_t slots4 = (int64_t)h->n_cus * 4, slots3 = (int64_t)h->n_cus * 3;
+    int64_t epw = n_groups / (2 * slots4);
     epw = epw < 1 ? 1 : epw > 4 ? 4 : epw;
     // the last `tail` groups go to short workgroups (dispatched last): a short drain
-    int64_t tail = 1024;        // one single-group workgroup per workgroup slot (256 CUs x 4): +0.9 % at N = 4096
+    int64_t tail = slots4;      // one single-group workgroup per workgroup slot: +0.9 % at N = 4096
     int64_t tail_epw = 1;
     // The Welch stream (windowed, hop = N/2, dense epochs) reads one half-frame twice per workgroup span — a span's first
     // half-frame is the previous span's last — so its spans are made long: ~256 frames per big workgroup while at least ~2.7
@@ -498,8 +505,8 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // workgroup per slot.  At K = 8 that is 32 epochs / 8 epochs / 6144 epochs: traffic 1.005 x the algorithmic bytes instead
     // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r03_welch_spans.txt).
     if (c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop) {
-      const int64_t slots = 768;
-      epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups / 2048);
+      const int64_t slots = slots3;
+      epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups * 3 / (8 * slots));   // >= 2.67 rounds of them
       epw = epw < 1 ? 1 : epw > 64 ? 64 : epw;
       tail_epw = epw / 4 < 1 ? 1 : epw / 4 > 8 ? 8 : epw / 4;
       tail = slots * tail_epw;
