@@ -109,10 +109,10 @@ int crn_cfg_load_ann(crn_cfg *cfg, const char *path) {
   if (!cfg || !path) return crn::fail(CRN_ERR_ARG, "crn_cfg_load_ann: null argument");
   FILE *f = std::fopen(path, "r");
   if (!f) return crn::fail(CRN_ERR_ARG, std::string("crn_cfg_load_ann: cannot read ") + path);
-  double v[55];
+  double v[56];
   int n = 0;
   char tok[128];
-  while (n < 55 && std::fscanf(f, "%127s", tok) == 1) {
+  while (n < 56 && std::fscanf(f, "%127s", tok) == 1) {   // (a 56th number is one too many: counted so that it is refused)
     if (tok[0] == '#') {  // comment: skip the rest of the line
       int ch;
       while ((ch = std::fgetc(f)) != EOF && ch != '\n') {}

@@ -27,9 +27,20 @@ def alt_row(label, a):
 
 rows = []
 h = load("headline")
-rows.append(row("**headline: 4096-pt energy × 3ch + NF, K=10, 28 672 epochs** — kernel specialised to the reference channel plan's 7 of 16 pass-3 rows", h))
-rows.append(alt_row("same batch, no row pruning (`config.alt.unpruned`: any other band table, or spectrum output on)", h["config"]["alt"]["unpruned"]))
-rows.append(alt_row("same kernel, SURVEY.md §8(d)'s 2 GiB batch (`config.alt.cfgH_2GiB_batch`, 6 553 epochs)", h["config"]["alt"]["cfgH_2GiB_batch"]))
+rows.append(row("**headline: 4096-pt energy × 3ch + NF, K=10, 28 672 epochs** — kernel specialised to the reference channel plan (pass 3 keeps 7 of 16 outputs per thread)", h))
+try:
+    rows.append(row("same batch, no pruning (`--variant 2`, its own run: any other band table, or spectrum output on)", load("headline_unpruned")))
+except Exception:
+    pass
+rows.append(alt_row("the same inside the headline run (`config.alt.unpruned`, 50 launches after the timed region)", h["config"]["alt"]["unpruned"]))
+rows.append(alt_row("same kernel, SURVEY.md §8(d)'s 2 GiB batch (`config.alt.cfgH_2GiB_batch`, 6 553 epochs), launches on one stream", h["config"]["alt"]["cfgH_2GiB_batch"]))
+if "cfgH_2GiB_batch_two_streams" in h["config"]["alt"]:
+    t = h["config"]["alt"]["cfgH_2GiB_batch_two_streams"]
+    rows.append(f'| the same 2 GiB batches launched alternately on two streams (`config.alt.cfgH_2GiB_batch_two_streams`: one launch\'s ramp and partly filled last round overlap its neighbour; span of 60 launches / 60) | {num(t["Msamples/s"])} | {t["ms_per_launch"]:.3f} per launch | {t["GB/s"]:.0f} | {100 * t["frac"]:.1f} |')
+try:
+    rows.append(row("same batch, every twiddle in registers at 3 workgroups per CU (`--variant 23`)", load("headline_all_twiddles_in_registers")))
+except Exception:
+    pass
 if "adc16_input" in h["config"]["alt"]:
     rows.append(alt_row("same batch and kernel, every sample rounded to the USRP's 16-bit wire format (`config.alt.adc16_input`: what the reference's radios deliver; §8)", h["config"]["alt"]["adc16_input"]))
 if "wire_format_sc16" in h["config"]["alt"]:
@@ -47,6 +58,7 @@ if "--write" in sys.argv:   # replace the GPU rows of DESIGN.md §6 (header .. t
     path = os.path.join(R, "DESIGN.md")
     lines = open(path).read().split("\n")
     a = next(i for i, ln in enumerate(lines) if ln.startswith("| Workload (8.75 GiB")) + 2
+    lines[a - 2] = lines[a - 2].replace("profiles/r02_bench_", f"profiles/{tag}_bench_")
     b = next(i for i, ln in enumerate(lines) if ln.startswith("| CPU oracle"))
     lines[a:b] = rows
     open(path, "w").write("\n".join(lines))
