@@ -39,6 +39,7 @@ struct crn_handle {
   int64_t mid_groups = -1;      // < 0 = automatic; epoch groups handed to the middle tier
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
+  std::atomic<int> n_rings{0};  // ingest rings created on this handle (they size their result buffers for cfg.n_bands)
   int n_cus = 256;              // compute units of cfg.device (workgroup slots = n_cus x workgroups per CU): read at creation
   unsigned acc_mask = 0xFFFFu;  // accumulator registers (bit j R3 + d) that hold a bin of some band (N = 4096: the 256-bin rows)
   // one device slab holding every table
@@ -112,6 +113,12 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // crn_sense_set_bands on a live handle): twiddles, window, the band plan in its three forms, thresholds, ANN weights.
 static int build_tables(crn_handle *h) {
   const crn_cfg &cfg = h->cfg;
+  // what this function derives from cfg besides the device slab: put back if the slab cannot be made (a live handle keeps working
+  // with its old plan: crn_sense_set_bands)
+  const double keep_wp = h->window_power;
+  const int keep_as = h->aligned_shift, keep_nre = h->n_row_entries;
+  const unsigned keep_am = h->acc_mask;
+  auto undo = [&] { h->window_power = keep_wp; h->aligned_shift = keep_as; h->n_row_entries = keep_nre; h->acc_mask = keep_am; };
   h->window_power = 0.0;
   h->aligned_shift = 0;
   h->acc_mask = 0xFFFFu;
@@ -241,10 +248,14 @@ static int build_tables(crn_handle *h) {
   for (auto &p : pieces) std::memcpy(host.data() + p.off, p.src, p.bytes);
   void *slab = nullptr;
   hipError_t e = hipMalloc(&slab, total);
-  if (e != hipSuccess) return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(tables): ") + hipGetErrorString(e));
+  if (e != hipSuccess) {
+    undo();
+    return crn::fail(CRN_ERR_NOMEM, std::string("hipMalloc(tables): ") + hipGetErrorString(e));
+  }
   e = hipMemcpy(slab, host.data(), total, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(slab);
+    undo();
     return crn::fail(CRN_ERR_DEVICE, std::string("hipMemcpy(tables): ") + hipGetErrorString(e));
   }
   // hipFree waits for the device: launches still reading the previous slab (crn_sense_set_bands on a live handle) finish first
@@ -323,6 +334,13 @@ int crn_sense_destroy(crn_handle *h) {
     if (h->t_stop[i]) (void)hipEventDestroy(h->t_stop[i]);
   }
   delete h;
+  return CRN_OK;
+}
+
+// internal (crn_ingest.cpp): a ring attaches to / detaches from its handle
+int crn_sense_ring_count(crn_handle *h, int delta) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  h->n_rings.fetch_add(delta, std::memory_order_relaxed);
   return CRN_OK;
 }
 
@@ -778,6 +796,9 @@ int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs,
     return crn::fail(CRN_ERR_ARG, "crn_sense_set_bands: a different number of bands needs its thresholds");
   }
   if (int rc = validate(&next)) return rc;   // same rules as crn_sense_create (DECIDE_ANN keeps its 4 bands, ref_band stays inside)
+  if (n_bands != h->cfg.n_bands && h->n_rings.load(std::memory_order_relaxed) > 0)
+    return crn::fail(CRN_ERR_STATE, "crn_sense_set_bands: an ingest ring on this handle was sized for the current number of bands "
+                                    "(destroy it, change the plan, create it again)");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const crn_cfg prev = h->cfg;
   h->cfg = next;

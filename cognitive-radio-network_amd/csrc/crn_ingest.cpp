@@ -102,10 +102,12 @@ struct crn_ingest {
   int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
   double lat_us_sum = 0.0, lat_us_max = 0.0;
   std::thread launcher;
+  bool attached = false;                   // counted on the handle (crn_sense_set_bands refuses to change n_bands under a ring)
 };
 
 // defined in crn_api.cpp
 extern "C" int crn_sense_cfg_of(crn_handle *h, crn_cfg *out);
+extern "C" int crn_sense_ring_count(crn_handle *h, int delta);
 
 namespace {
 
@@ -369,6 +371,8 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   if (const char *e = std::getenv("CRN_INGEST_SPIN_US")) g->spin_us = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("CRN_INGEST_ZEROCOPY_BYTES")) g->zero_copy_bytes = (size_t)std::max(0ll, std::atoll(e));
   g->launcher = std::thread(launcher_main, g);
+  (void)crn_sense_ring_count(h, +1);
+  g->attached = true;
   *out = g;
   return CRN_OK;
 }
@@ -541,6 +545,7 @@ int crn_ingest_destroy(crn_ingest *g) {
     if (b.done) (void)hipEventDestroy(b.done);
   }
   if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->attached) (void)crn_sense_ring_count(g->h, -1);
   delete g;
   return CRN_OK;
 }

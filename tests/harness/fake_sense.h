@@ -29,6 +29,8 @@ extern "C" {
 const char *crn_last_error(void) { return crn::g_err.c_str(); }
 struct crn_handle { crn_cfg cfg; };
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
+static std::atomic<int> g_fake_rings_attached{0};
+int crn_sense_ring_count(crn_handle *, int delta) { g_fake_rings_attached += delta; return CRN_OK; }
 static std::atomic<long long> g_fake_launches{0};
 static std::atomic<int> g_fake_last_L{0};
 static std::atomic<long long> g_fake_last_stride{0};

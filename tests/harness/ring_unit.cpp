@@ -378,6 +378,7 @@ int main() {
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
     g_fake_gpu_latency_ns = 0;
   }
+  REQUIRE(g_fake_rings_attached.load() == 0);   // every ring that attached to its handle detached again
   printf("ring_unit: ok\n");
   return 0;
 }

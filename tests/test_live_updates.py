@@ -116,6 +116,12 @@ def test_set_bands_equals_a_fresh_handle(built, n):
         s.set_bands([(0, n + 1, 0)], 1, [1.0])
     with pytest.raises(cs.CrnError):
         s.set_bands([(0, 8, 0), (8, 16, 1)], 2, None)          # another number of bands needs its thresholds
+    ring = cs.Ingest(s, 1, n, 1)                               # a ring sized its result buffers for 4 bands:
+    with pytest.raises(cs.CrnError, match="ingest ring"):
+        s.set_bands([(0, 8, 0), (8, 16, 1)], 2, [1.0, 1.0])    # ... the number of bands cannot change under it
+    s.set_bands(plans[0][0], 4, plans[0][2])                   # the plan can
+    ring.close()
+    s.set_bands([(ref_plan.segs[i].lo, ref_plan.segs[i].hi, ref_plan.segs[i].band) for i in range(5)], 4, [ref_plan.thresh[b] for b in range(4)])
     assert np.array_equal(s.run_host(iq, n_epochs)["features"], first["features"])
     s.close()
 
