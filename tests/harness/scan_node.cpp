@@ -8,6 +8,9 @@
 // traffic on its device (the reference's Markov primary-user model), and per step runs the sensing kernel into a slot of
 // the communicator and queues the all-gather on the side stream; at the end it checks that its own block sits unchanged at
 // its place in the gathered vector and prints one line.
+// crn_comm_create is collective and — like ncclCommInitRank under it — cannot tell the other ranks about a local failure: a rank
+// that fails before it would leave the others waiting inside the collective.  So the ranks first AGREE, over the same out-of-band
+// channel that carries the id (files here), that every one of them finished its local set-up; if one did not, all of them stop.
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <math.h>
@@ -37,6 +40,34 @@
     }                                                                           \
   } while (0)
 
+// Every rank publishes "<id_file>.rank<r>" = 1 (local set-up done) or 0 (failed), then waits for all of them: true only if every
+// rank said 1 within the time limit.
+static bool all_ranks_ready(const char *id_file, int rank, int world, bool ok) {
+  char path[4096], tmp[4200];
+  snprintf(path, sizeof(path), "%s.rank%d", id_file, rank);
+  snprintf(tmp, sizeof(tmp), "%s.tmp", path);
+  FILE *f = fopen(tmp, "w");
+  if (!f) return false;
+  fputc(ok ? '1' : '0', f);
+  fclose(f);
+  if (rename(tmp, path) != 0) return false;
+  bool all = ok;
+  for (int r = 0; r < world && all; r++) {
+    snprintf(path, sizeof(path), "%s.rank%d", id_file, r);
+    int c = EOF;
+    for (int tries = 0; tries < 1200 && c == EOF; tries++) {   // up to 2 minutes per rank
+      if ((f = fopen(path, "r")) != NULL) {
+        c = fgetc(f);
+        fclose(f);
+      }
+      if (c == EOF) usleep(100000);
+    }
+    all = c == '1';
+    if (!all) fprintf(stderr, "scan_node: rank %d: rank %d %s: stopping before the collective\n", rank, r, c == '0' ? "failed its set-up" : "never reported");
+  }
+  return all;
+}
+
 static int env_int(const char *k, int d) {
   const char *v = getenv(k);
   return v ? atoi(v) : d;
@@ -60,21 +91,25 @@ int main(int argc, char **argv) {
   const int64_t E = (int64_t)n_streams * eps;
 
   crn_cfg cfg;
+  crn_handle *h = NULL;
+  hipStream_t stream = NULL;
+  float *d_iq = NULL, *d_feat = NULL;
+  int32_t *d_truth = NULL, *d_dec = NULL;
+  int64_t spe = 0;
+  uint8_t id[CRN_COMM_ID_BYTES];
+  // everything a rank does on its own, before the first collective
+  auto local_setup = [&]() -> int {
   CHECK(crn_cfg_welch(&cfg, 4096, 8, 64));
   // per-band threshold = 4 x the noise floor, measured below on this node's own streams (NF_est = the
   // median band energy); until then nothing is flagged
   for (int b = 0; b < 64; b++) cfg.thresh[b] = INFINITY;
   cfg.device = device;
-  crn_handle *h = NULL;
   CHECK(crn_sense_create(&cfg, &h));
   HIP(hipSetDevice(device));
-  hipStream_t stream;
   HIP(hipStreamCreate(&stream));
 
-  const int64_t spe = (int64_t)cfg.frames_per_epoch * cfg.hop;            // dense epochs, hop N/2
+  spe = (int64_t)cfg.frames_per_epoch * cfg.hop;            // dense epochs, hop N/2
   const int64_t n_samples = E * spe + (cfg.fft_len - cfg.hop);
-  float *d_iq = NULL, *d_feat = NULL;
-  int32_t *d_truth = NULL, *d_dec = NULL;
   HIP(hipMalloc((void **)&d_iq, (size_t)n_samples * 8));
   HIP(hipMemset(d_iq, 0, (size_t)n_samples * 8));
   HIP(hipMalloc((void **)&d_truth, (size_t)E * 4));
@@ -106,7 +141,6 @@ int main(int argc, char **argv) {
   }
 
   // the RCCL unique id: rank 0 makes it, the others pick it up from the file
-  uint8_t id[CRN_COMM_ID_BYTES];
   if (rank == 0) {
     CHECK(crn_comm_unique_id(id));
     char tmp[4096];
@@ -124,6 +158,10 @@ int main(int argc, char **argv) {
     }
     fclose(f);
   }
+  return 0;
+  };
+  const int setup_rc = local_setup();
+  if (!all_ranks_ready(id_file, rank, world, setup_rc == 0)) return 1;
   crn_comm *comm = NULL;
   CHECK(crn_comm_create(device, rank, world, id, E * 64, 2, &comm));
 

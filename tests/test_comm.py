@@ -112,3 +112,27 @@ def test_scan_node_two_processes_on_one_gpu(built):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank")]
     assert len(lines) == 2 and any("rank 0/2" in ln for ln in lines) and any("rank 1/2" in ln for ln in lines), out.stdout
+
+
+@pytest.mark.gpu
+def test_scan_node_ranks_stop_together_when_one_fails_its_setup(built, tmp_path):
+    """crn_comm_create is collective and cannot report a peer's local failure: tests/harness/scan_node.cpp therefore has its ranks agree
+    (files beside the id file) that every one finished its local set-up before any of them enters the collective.  Two ranks, one of
+    which fails its set-up (a device ordinal that does not exist): BOTH exit non-zero within seconds — the healthy one is not left
+    waiting inside ncclCommInitRank."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "harness", "scan_node")
+    fake = os.path.join(root, "tests", "harness", "libfake_rccl_mp.so")
+    idf = str(tmp_path / "id")
+    t0 = time.time()
+    procs = []
+    for r, dev in ((0, 0), (1, 99)):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(dev), CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
+        procs.append(subprocess.Popen([exe, "8", "32", "2", idf], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=150) for p in procs]
+    assert all(p.returncode != 0 for p in procs), [p.returncode for p in procs]
+    assert time.time() - t0 < 120
+    assert "failed its set-up" in outs[0][1] and "stopping before the collective" in outs[0][1]
+

@@ -11,5 +11,5 @@ for r in $(seq 0 $((N - 1))); do
 done
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
-rm -f "$ID"
+rm -f "$ID" "$ID".rank*
 exit $rc
