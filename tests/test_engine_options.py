@@ -196,3 +196,47 @@ def test_cfg0_thousand_epochs_through_the_engine_surface(built, tmp_path, args, 
     assert np.array_equal(got_d, wd) and np.array_equal(wd, picks)
     assert (np.abs(got_f - want["features"]) / np.abs(want["features"])).max() < 1e-5
     assert all(float(w[5]) == TX[int(d)] for w, d in zip(full, wd))
+
+
+@pytest.mark.parametrize("args,L", [
+    (["-m", "scan", "-n", "1024", "-c", "2", "-a", "0"], 512),
+    (["-m", "welch", "-n", "2048", "-k", "4", "-b", "2"], 364),
+    (["-m", "energy", "-n", "4096", "-k", "3", "-t", "8", "-a", "0"], 4096),
+    (["-m", "ref", "-n", "2048", "-k", "12", "-b", "3"], 1000),
+], ids=["scan synchronous", "welch batched", "energy 4096 K=3", "ref 2048 K=12 batched"])
+def test_engine_option_combinations_against_the_oracle(built, tmp_path, args, L):
+    """Less usual combinations of the ce_args — synchronous scan with calibration, batched Welch, short epochs, long epochs at another
+    size — each against the oracle run with the configuration the options stand for."""
+    opt = dict(zip(args[::2], args[1::2]))
+    n, mode = int(opt["-n"]), opt["-m"]
+    K = int(opt.get("-k", 8 if mode == "scan" else 10))
+    lam = float(opt.get("-t", 4))
+    if mode == "scan":
+        cfg = cs.cfg_welch_scaled(n, K, lam)          # traffic on the reference's channels
+    elif mode == "welch":
+        cfg = cs.cfg_welch_scaled(n, K, lam)
+    elif mode == "energy":
+        cfg = cs.cfg_energy_scaled(n, lam)
+        cfg.frames_per_epoch = K
+    else:
+        cfg = cs.cfg_reference_scaled(n)
+        cfg.frames_per_epoch = K
+    n_epochs = 9
+    if cfg.hop != cfg.fft_len:
+        iq, picks, P = _welch_stream(cfg, n_epochs, L, seed=21)
+        stride, spf = P * L, n
+    else:
+        iq, picks = signals.make_epochs(cfg, n_epochs, seed=22, L=L)
+        stride, spf = 0, L
+    out = _run_harness("engine_harness", ["IQ", str(L), "-g", "0", "-v", "0"] + args, tmp_path, iq)
+    _, allp = _epoch_lines(out)
+    calib = int(opt.get("-c", 0))
+    assert [int(w[1]) for w in allp] == list(range(n_epochs - calib))
+    got = np.array([int(w[3]) for w in allp])
+    if mode == "ref":
+        want = orc.run(cfg, iq, n_epochs, L=spf, epoch_stride=stride)["decision"]
+    elif mode == "scan":
+        want = picks            # (thresholds come from the engine's own calibration: the driven channel is what must be found)
+    else:
+        want = _first_occupied(orc.run(cfg, iq, n_epochs, L=spf, epoch_stride=stride)["occupancy"])
+    assert np.array_equal(got, np.asarray(want)[calib:]), (got, want)
