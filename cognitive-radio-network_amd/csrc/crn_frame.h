@@ -133,6 +133,8 @@ enum : int {
   kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
   kAlignedBands = 65536, // N = 4096, equal contiguous bands of 64 / 128 / 256 bins (p.aligned_shift): band sums by DPP + one barrier
   kSc16 = 131072,   // samples in HBM are the radio's wire format (two int16 per complex sample, 4 bytes): converted in pass 1
+  kRowsRT = 262144, // N = 4096: pass 3 and the accumulate skip, by wave-uniform branches on the launch's acc_mask, the 256-bin rows no
+                    // band of the handle's table touches — the pruning of kRows for ANY sparse band table, decided at run time
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -160,6 +162,7 @@ struct FrameCtx {
   unsigned lds_base;  // LDS byte offset of the dynamic segment (SGPR); the band table copy sits behind tw2
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
+  unsigned rt_mask;   // kRowsRT: the launch's acc_mask (wave-uniform)
   float Kf, invK;
 };
 
@@ -424,9 +427,72 @@ CRN_DEV void ph_pass3_pruned(cx (&u)[16], cx (&v)[16]) {
   }
 }
 
+// one bin's contribution to its accumulator (reference: fft_avg[i] += cabsf(X[i]) / K, CE_Predictive_Node.cpp:152-154)
+template <class C>
+CRN_DEV void acc_bin(float &acc, cx x, float invK) {
+  if constexpr (C::MAG) acc = fmaf(__builtin_amdgcn_sqrtf(fmaf(x.x, x.x, x.y * x.y)), invK, acc);
+  else acc = fmaf(x.y, x.y, fmaf(x.x, x.x, acc));
+}
+
+// Pass 3 + accumulate at N = 4096 with the rows to form chosen at RUN time: `c.rt_mask` (bit d = some band touches bins
+// [256 d, 256 d + 256)) is the same for every thread of the launch, so each test below is a scalar branch.  Level A and the layout
+// are dft16's; per output the operations are dft16_level_b's, so a row that is formed holds exactly what the full kernel forms.
+template <class C>
+CRN_DEV void ph_pass3_acc_rt(cx (&u)[16], FrameCtx<C> &c) {
+  static_assert(C::R3 == 16, "run-time row pruning: N = 4096 (one 256-bin row per accumulator register)");
+  using m = M<C::PK>;
+  const unsigned mask = c.rt_mask;
+  cx y[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = u[i];
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0++) dft4<C::PK>(y[r0], y[r0 + 4], y[r0 + 8], y[r0 + 12]);
+  const cx w1 = {CRN_C1, -CRN_S1}, w3 = {CRN_S1, -CRN_C1}, w9 = {-CRN_C1, CRN_S1};
+  static_for<4>([&](auto ac) {
+    constexpr int a0 = decltype(ac)::value;
+    const unsigned m4 = mask >> a0;                       // bits 0 / 4 / 8 / 12: rows a0, a0 + 4, a0 + 8, a0 + 12
+    if ((m4 & 0x1111u) == 0) return;                      // none of this group's four rows
+    const cx b0 = y[4 * a0];
+    if constexpr (a0 == 2) {
+      const cx p = m::add_mj(y[9], y[9]), q = m::sub_mj(y[11], y[11]);
+      if ((m4 & 0x0101u) != 0) {
+        const cx s02 = m::add_mj(b0, y[10]), uu = m::sub(p, q);
+        if ((m4 & 0x0001u) != 0) acc_bin<C>(c.acc[a0 + 0], m::fma_h(uu, s02), c.invK);
+        if ((m4 & 0x0100u) != 0) acc_bin<C>(c.acc[a0 + 8], m::fms_h(uu, s02), c.invK);
+      }
+      if ((m4 & 0x1010u) != 0) {
+        const cx d02 = m::sub_mj(b0, y[10]), vv = m::add(p, q);
+        if ((m4 & 0x0010u) != 0) acc_bin<C>(c.acc[a0 + 4], m::fma_h_mj(vv, d02), c.invK);
+        if ((m4 & 0x1000u) != 0) acc_bin<C>(c.acc[a0 + 12], m::fms_h_mj(vv, d02), c.invK);
+      }
+    } else {
+      cx b1 = y[4 * a0 + 1], b3 = y[4 * a0 + 3];
+      if constexpr (a0 == 1) { b1 = m::mul_c(b1, w1); b3 = m::mul_c(b3, w3); }
+      if constexpr (a0 == 3) { b1 = m::mul_c(b1, w3); b3 = m::mul_c(b3, w9); }
+      const cx r = a0 == 1 ? m::add_mj(y[4 * a0 + 2], y[4 * a0 + 2]) : a0 == 3 ? m::sub_mj(y[4 * a0 + 2], y[4 * a0 + 2]) : y[4 * a0 + 2];
+      if ((m4 & 0x0101u) != 0) {
+        const cx s02 = a0 == 0 ? m::add(b0, r) : a0 == 1 ? m::fma_h(r, b0) : m::fms_h(r, b0);
+        const cx s13 = m::add(b1, b3);
+        if ((m4 & 0x0001u) != 0) acc_bin<C>(c.acc[a0 + 0], m::add(s02, s13), c.invK);
+        if ((m4 & 0x0100u) != 0) acc_bin<C>(c.acc[a0 + 8], m::sub(s02, s13), c.invK);
+      }
+      if ((m4 & 0x1010u) != 0) {
+        const cx d02 = a0 == 0 ? m::sub(b0, r) : a0 == 1 ? m::fms_h(r, b0) : m::fma_h(r, b0);
+        const cx d13 = m::sub(b1, b3);
+        if ((m4 & 0x0010u) != 0) acc_bin<C>(c.acc[a0 + 4], m::add_mj(d02, d13), c.invK);
+        if ((m4 & 0x1000u) != 0) acc_bin<C>(c.acc[a0 + 12], m::sub_mj(d02, d13), c.invK);
+      }
+    }
+  });
+}
+
 // pass 3 + per-bin accumulate: v[j * R3 + d] is bin a + 16 (m_lo J + j) + 256 d
 template <class C>
 CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+  if constexpr ((C::OPT & kRowsRT) != 0 && C::R3 == 16) {
+    ph_pass3_acc_rt<C>(u, c);
+    return;
+  }
   cx v[16];
   constexpr unsigned MASK = acc_mask<C>();
   if constexpr (MASK == 0xFFFFu) {

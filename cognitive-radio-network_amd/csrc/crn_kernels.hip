@@ -55,6 +55,7 @@ static constexpr VariantDesc kVariants[] = {
     /* 21 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: early pass-2 twiddle reads alone
     /* 22 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the plain form (16 window registers, twiddles read where used)
     /* 23 */ {1, 1, 1, 0, 3, 0, 1},  // the default's work at 3 workgroups/CU with all twiddles in registers (fewer instructions, less LDS)
+    /* 24 */ {1, 1, 1, 1, 4, 0, 1},  // the default with its pass-3 rows chosen at run time from the handle's band table (kRowsRT)
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -143,6 +144,10 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
 #endif
+      case 24:  // rows chosen at run time (any band table with a register close); otherwise the full kernel
+        if (reg_bands(p))
+          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRowsRT | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
       case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
         if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
@@ -172,7 +177,7 @@ bool sense_variant_available(int v) {
 #ifdef CRN_AB_VARIANTS
   return v >= 0 && v <= kNumVariants;
 #else
-  return v == 0 || v == kDefaultVariant || v == 2 || v == 23;
+  return v == 0 || v == kDefaultVariant || v == 2 || v == 23 || v == 24;
 #endif
 }
 

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.a = a;
   c.m_lo = m_lo;
   c.L = p.L;
+  c.rt_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)p.acc_mask);
   c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.grp_epoch_stride = 1;
