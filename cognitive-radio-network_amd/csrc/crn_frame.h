@@ -133,8 +133,10 @@ enum : int {
   kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
   kAlignedBands = 65536, // N = 4096, equal contiguous bands of 64 / 128 / 256 bins (p.aligned_shift): band sums by DPP + one barrier
   kSc16 = 131072,   // samples in HBM are the radio's wire format (two int16 per complex sample, 4 bytes): converted in pass 1
-  kRowsRT = 262144, // N = 4096: pass 3 and the accumulate skip, by wave-uniform branches on the launch's acc_mask, the 256-bin rows no
-                    // band of the handle's table touches — the pruning of kRows for ANY sparse band table, decided at run time
+  kRowsRT = 262144, // A/B build only (variant 24), N = 4096: pass 3 and the accumulate skip, by wave-uniform branches on the launch's
+                    // acc_mask, the 256-bin rows no band touches — kRows' pruning decided at run time.  Measured SLOWER than forming
+                    // every row (80.3 vs 82.4 % on the reference plan, 77.0 vs 81.0 % on a dense one): a dozen scalar branches
+                    // per frame cost an in-order wave more than the 9 x 3 instructions they skip; not shipped
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -434,6 +436,7 @@ CRN_DEV void acc_bin(float &acc, cx x, float invK) {
   else acc = fmaf(x.y, x.y, fmaf(x.x, x.x, acc));
 }
 
+#ifdef CRN_AB_VARIANTS
 // Pass 3 + accumulate at N = 4096 with the rows to form chosen at RUN time: `c.rt_mask` (bit d = some band touches bins
 // [256 d, 256 d + 256)) is the same for every thread of the launch, so each test below is a scalar branch.  Level A and the layout
 // are dft16's; per output the operations are dft16_level_b's, so a row that is formed holds exactly what the full kernel forms.
@@ -486,13 +489,17 @@ CRN_DEV void ph_pass3_acc_rt(cx (&u)[16], FrameCtx<C> &c) {
   });
 }
 
+#endif  // CRN_AB_VARIANTS
+
 // pass 3 + per-bin accumulate: v[j * R3 + d] is bin a + 16 (m_lo J + j) + 256 d
 template <class C>
 CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+#ifdef CRN_AB_VARIANTS
   if constexpr ((C::OPT & kRowsRT) != 0 && C::R3 == 16) {
     ph_pass3_acc_rt<C>(u, c);
     return;
   }
+#endif
   cx v[16];
   constexpr unsigned MASK = acc_mask<C>();
   if constexpr (MASK == 0xFFFFu) {

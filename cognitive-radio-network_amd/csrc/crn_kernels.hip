@@ -144,10 +144,12 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
       case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
 #endif
+#ifdef CRN_AB_VARIANTS
       case 24:  // rows chosen at run time (any band table with a register close); otherwise the full kernel
         if (reg_bands(p))
           return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRowsRT | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
         return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
+#endif
       case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
         if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
           return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
@@ -177,7 +179,7 @@ bool sense_variant_available(int v) {
 #ifdef CRN_AB_VARIANTS
   return v >= 0 && v <= kNumVariants;
 #else
-  return v == 0 || v == kDefaultVariant || v == 2 || v == 23 || v == 24;
+  return v == 0 || v == kDefaultVariant || v == 2 || v == 23;
 #endif
 }
 

@@ -24,7 +24,7 @@ def per_bin_err(spec, floor=1e-2):
 
 
 base = None
-for v in list(range(0, 11)) + [13, 23]:      # 11, 12, 14-18: ablations / trace build, not sensing results
+for v in list(range(0, 11)) + [13, 23, 24]:      # 11, 12, 14-18: ablations / trace build, not sensing results
     s = cs.Sensor(cfg)
     s.set_variant(v)
     got = s.run_host(iq, n_epochs, want_spectrum=True)

@@ -355,7 +355,7 @@ def test_shipped_library_carries_no_measurement_variants(built):
         assert np.allclose(got["features"], base["features"], rtol=2e-6, atol=0), v
         assert np.array_equal(got["occupancy"], base["occupancy"]), v
     s = cs.Sensor(cfg)
-    for v in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22):
+    for v in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24):
         with pytest.raises(cs.CrnError, match="measurement variant"):
             s.set_variant(v)
     s.set_variant(100 + 2)       # launch geometry overrides stay (they select no other kernel)

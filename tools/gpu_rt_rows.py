@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cognitive-radio-network_amd")]
+os.environ.setdefault("CRN_SENSE_AB", "1")   # variant 24 is a measurement variant: libcrnsense_ab.so
 import crnsense as cs  # noqa: E402
 
 dev = torch.device("cuda", 0)
