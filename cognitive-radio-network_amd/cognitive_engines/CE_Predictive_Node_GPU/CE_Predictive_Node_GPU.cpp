@@ -294,8 +294,10 @@ void CE_Predictive_Node_GPU::execute() {
       if (L != frame_len && fft_counter == 0) {   // UHD packet size is constant in practice: once, at the first packet
         const int rc = crn_ingest_set_packet_len(ring, L);
         if (rc == CRN_ERR_BUSY) { packets_dropped++; return; }
-        if (rc != CRN_OK) die_crn();
-        frame_len = L;
+        if (rc == CRN_OK) frame_len = L;
+        else if (rc != CRN_ERR_STATE) die_crn();
+        // (CRN_ERR_STATE: with -b > 1 earlier epochs of the batch are staged at the old length; this epoch keeps that length too —
+        // its packets are truncated / zero-padded below — and the new length takes over with the next batch)
       }
       if (L != frame_len) {
         // a different length INSIDE an epoch: the epoch keeps its length — the packet is truncated or zero-padded to it, as

@@ -311,6 +311,42 @@ int main() {
     e->release();
     delete e;
   }
+  // ---- -b 3 and a packet length that changes between the epochs of one batch: the batch keeps its length (packets padded), nothing dies ----
+  {
+    ECRd ecr;
+    CE_Predictive_Node_GPU *e = make_engine(ecr, {"-g", "0", "-v", "0", "-b", "3"});
+    std::vector<std::complex<float> > p364(364), p300(300);
+    ecr.ce_usrp_rx_buffer = p364.data();
+    ecr.ce_usrp_rx_buffer_length = 364;
+    exec(ecr, ECRd::TIMEOUT);
+    auto feed = [&](std::vector<std::complex<float> > &buf, int d) {
+      while (!ecr.ce_sensing_flag) exec(ecr, ECRd::TIMEOUT);
+      ecr.ce_usrp_rx_buffer = buf.data();
+      ecr.ce_usrp_rx_buffer_length = (int)buf.size();
+      for (int p = 0; p < 10; p++) {
+        for (size_t i = 0; i < buf.size(); i++) buf[i] = std::complex<float>((float)d, 0.25f);
+        do {
+          e->packets_dropped = 0;
+          exec(ecr, ECRd::USRP_RX_SAMPS);
+        } while (e->packets_dropped);
+      }
+    };
+    feed(p364, 1);
+    feed(p300, 2);     // set_packet_len is refused (an epoch of the batch is staged): padded to 364, the run goes on
+    feed(p300, 3);
+    for (int spin = 0; e->epochs_closed < 3 && spin < 2000000; spin++) exec(ecr, ECRd::TIMEOUT);
+    REQUIRE(e->epochs_closed == 3);
+    REQUIRE(e->recent_decisions[0] == 1 && e->recent_decisions[1] == 2 && e->recent_decisions[2] == 3);
+    REQUIRE(e->features[0] == 10.0f * 300 * 3.25f);     // the padded epoch's checksum: 300 samples a packet, zeros behind them
+    REQUIRE(g_fake_last_L.load() == 364);                // launched at the batch's length
+    feed(p300, 1);     // the next batch starts at the new length
+    feed(p300, 2);
+    feed(p300, 3);
+    for (int spin = 0; e->epochs_closed < 6 && spin < 2000000; spin++) exec(ecr, ECRd::TIMEOUT);
+    REQUIRE(e->epochs_closed == 6 && g_fake_last_L.load() == 300);
+    e->release();
+    delete e;
+  }
   // ---- -m welch: the packets of a sensing period are one contiguous run; frames of N cut from it with hop N/2 --------------------
   for (int sync = 0; sync < 2; sync++) {
     ECRd ecr;
