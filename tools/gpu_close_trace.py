@@ -17,10 +17,11 @@ iq = torch.zeros(cs.samples_needed(cfg, E) * 2, dtype=torch.float32, device=dev)
 feats = torch.empty(E, cfg.n_bands, dtype=torch.float32, device=dev)
 occ = torch.empty(E, cfg.n_bands, dtype=torch.uint8, device=dev)
 dec = torch.empty(E, dtype=torch.int32, device=dev)
-tr = torch.zeros(E, 3, dtype=torch.int64, device=dev)
+tr4 = torch.zeros(E * 4, dtype=torch.int64, device=dev)   # [E][3] close stamps + one start stamp per workgroup behind them
+tr = tr4[:E * 3].view(E, 3)
 stream = torch.cuda.current_stream().cuda_stream
 s.synth_fill_device(iq.data_ptr(), E, spe, seed=1, stream=stream)
-outs = {"features": feats.data_ptr(), "ann_out": tr.data_ptr(), "decision": dec.data_ptr(), "occupancy": occ.data_ptr(), "spectrum": 0}
+outs = {"features": feats.data_ptr(), "ann_out": tr4.data_ptr(), "decision": dec.data_ptr(), "occupancy": occ.data_ptr(), "spectrum": 0}
 s.set_variant(17)
 for _ in range(40):
     s.run_device(iq.data_ptr(), E, 4096, outs, stream=stream)
