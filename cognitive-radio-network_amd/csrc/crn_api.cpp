@@ -37,18 +37,6 @@ struct crn_handle {
   int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
   int mid_groups_per_wg = -1;   // < 0 = automatic; epoch groups per middle-tier workgroup (0: no middle tier)
   int64_t mid_groups = -1;      // < 0 = automatic; epoch groups handed to the middle tier
-  int64_t relay_groups = -1;    // < 0 = automatic; epoch groups at the end of a launch whose frames are cut into relayed runs
-  int relay_segments = 0;       // 0 = automatic; runs per relayed group
-  // relay buffers, one per stream that launched (launches on one stream follow each other; launches on different streams overlap)
-  struct RelayBuf {
-    void *stream;
-    unsigned *ctl;
-    float *acc;
-  };
-  static constexpr int kRelayStreams = 8;
-  std::mutex relay_mu;
-  std::vector<RelayBuf> relays;
-  int64_t relay_cap = 0;        // groups a relay buffer holds: 2 x the plain kernels' workgroup slots
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   std::atomic<int> n_rings{0};  // ingest rings created on this handle (they size their result buffers for cfg.n_bands)
@@ -341,7 +329,6 @@ int crn_sense_destroy(crn_handle *h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->d_nf_scratch) (void)hipFree(h->d_nf_scratch);
-  for (auto &r : h->relays) (void)hipFree(r.ctl);
   for (int i = 0; i < crn_handle::kTimedSlots; i++) {
     if (h->t_start[i]) (void)hipEventDestroy(h->t_start[i]);
     if (h->t_stop[i]) (void)hipEventDestroy(h->t_stop[i]);
@@ -384,14 +371,6 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   }
   if (variant >= 500 && variant <= 564) {  // A/B: 500 + n = n x 256 epoch groups in the middle tier
     h->mid_groups = (int64_t)(variant - 500) * 256;
-    return CRN_OK;
-  }
-  if (variant >= 600 && variant <= 664) {  // A/B: 600 + n = n x 64 epoch groups in the relayed end (600 = none)
-    h->relay_groups = (int64_t)(variant - 600) * 64;
-    return CRN_OK;
-  }
-  if (variant >= 700 && variant <= 708) {  // A/B: 700 + n = n runs per relayed group (700 = automatic)
-    h->relay_segments = variant - 700;
     return CRN_OK;
   }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
@@ -508,42 +487,6 @@ int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out) {
   return CRN_OK;
 }
 
-namespace {
-// The relay buffer of a stream (SenseParams::relay_ctl / relay_acc): created at the stream's first launch, 16 KiB per group.
-// None while the stream is being captured into a graph (no allocation there, and replays of one graph could overlap), nor
-// beyond kRelayStreams streams: the launch then simply has no relayed end.
-bool relay_for(crn_handle *h, hipStream_t stream, unsigned **ctl, float **acc) {
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  if (cs != hipStreamCaptureStatusNone) return false;
-  std::lock_guard<std::mutex> lk(h->relay_mu);
-  for (const auto &r : h->relays)
-    if (r.stream == (void *)stream) {
-      *ctl = r.ctl;
-      *acc = r.acc;
-      return true;
-    }
-  if ((int)h->relays.size() >= crn_handle::kRelayStreams) return false;
-  if (h->relay_cap == 0) h->relay_cap = (int64_t)h->n_cus * 8;
-  const size_t ctl_bytes = ((size_t)(16 + h->relay_cap) * sizeof(unsigned) + 255) & ~(size_t)255;
-  void *d = nullptr;
-  if (hipMalloc(&d, ctl_bytes + (size_t)h->relay_cap * 16 * 256 * sizeof(float)) != hipSuccess ||
-      hipMemset(d, 0, ctl_bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    if (d) (void)hipFree(d);
-    return false;
-  }
-  crn_handle::RelayBuf r{(void *)stream, static_cast<unsigned *>(d), reinterpret_cast<float *>(static_cast<char *>(d) + ctl_bytes)};
-  h->relays.push_back(r);
-  *ctl = r.ctl;
-  *acc = r.acc;
-  return true;
-}
-}  // namespace
-
 static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                            int64_t epoch_stride, const crn_out *d_out, void *stream, bool sc16) {
   if (!h || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / outputs");
@@ -589,8 +532,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // rounds of them remain over the 768 slots (3 workgroups per CU), a quarter of that per tail workgroup, one tail
     // workgroup per slot.  At K = 8 that is 32 epochs / 8 epochs / 6144 epochs: traffic 1.005 x the algorithmic bytes instead
     // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r03_welch_spans.txt).
-    const bool welch_stream = c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop;
-    if (welch_stream) {
+    if (c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop) {
       const int64_t slots = slots3;
       epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups * 3 / (8 * slots));   // >= 2.67 rounds of them
       epw = epw < 1 ? 1 : epw > 64 ? 64 : epw;
@@ -608,21 +550,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     if (mid > (n_groups - tail) / 2) mid = (n_groups - tail) / 2;
     p.mid_groups_per_wg = (int)mid_epw;
     p.n_mid_wgs = mid_epw > 0 ? mid / mid_epw : 0;
-    // The relayed end (plain streams only: launch_cfg drops it for the Welch stream): the last groups' frames in runs of K / S,
-    // one workgroup per run, so that the machine drains in steps of a fraction of an epoch.
-    int64_t relay = 0;
-    int segs = h->relay_segments > 0 ? h->relay_segments : 2;
-    if (h->relay_groups >= 0) relay = h->relay_groups;
-    if (segs > c.frames_per_epoch) segs = c.frames_per_epoch;
-    if (relay > n_groups - tail) relay = n_groups - tail;
-    if (segs < 2 || welch_stream) relay = 0;
-    if (relay > 0) {
-      if (relay_for(h, static_cast<hipStream_t>(stream), &p.relay_ctl, &p.relay_acc)) {
-        p.n_relay_groups = std::min(relay, h->relay_cap);
-        p.relay_segments = segs;
-      }
-    }
-    p.n_big_wgs = (n_groups - p.n_relay_groups - tail - p.n_mid_wgs * mid_epw) / p.groups_per_wg;
+    p.n_big_wgs = (n_groups - tail - p.n_mid_wgs * mid_epw) / p.groups_per_wg;
   }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;

@@ -28,15 +28,6 @@ struct SenseParams {
   int mid_groups_per_wg;
   int tail_groups_per_wg;  // >= 1 (1 for the plain kernels; the Welch stream, which re-reads one half-frame per workgroup span,
                            // keeps its tail workgroups longer)
-  // The relayed end of the stream: the last n_relay_groups epoch groups are cut into relay_segments runs of frames, one workgroup
-  // per run; a run hands its accumulator registers to the next through `relay_acc` ([group][16][256] floats: the same values in the
-  // same order as one workgroup would hold them, so the results are bit-identical) and the last run closes the epoch.  The kernel's
-  // final scheduling unit is then a fraction of an epoch (the drain of the machine is what a launch loses: DESIGN.md §5).
-  long long n_relay_groups;   // 0: none
-  long long first_relay_wg;   // workgroups from this index on take relay roles (by ticket, in the order they start): set by launch_cfg
-  int relay_segments;         // 2 .. 8 when n_relay_groups > 0
-  unsigned *relay_ctl;        // [0] ticket counter (left at 0 by the last role taken), [16 + group] runs finished (reset by the last run)
-  float *relay_acc;
   // tables (device, built at crn_sense_create)
   const float2 *tw1;       // [17][T]  W_N^{t a}, a = 0..16
   const float2 *tw2;       // [16][R3] W_T^{m c}

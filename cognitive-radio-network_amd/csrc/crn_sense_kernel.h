@@ -26,72 +26,18 @@ struct StreamSpan {
 template <int R3>
 CRN_DEV StreamSpan stream_span(const SenseParams &p) {
   using G = Geo<R3>;
-  // the groups ahead of the relayed end
-  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS - p.n_relay_groups;
-  // three tiers in dispatch order: big spans, then (optionally) middle ones, then the short tail; relay roles come last
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
+  // three tiers in dispatch order: big spans, then (optionally) middle ones, then the short tail
   const long long b = (long long)blockIdx.x;
-  StreamSpan s;
-  if (b >= p.first_relay_wg) {   // one run of one group's frames: the group index is added from the ticket
-    s.epw = 1;
-    s.g0 = n_groups;
-    s.n_local = 1;
-    return s;
-  }
   const bool big = b < p.n_big_wgs, mid = !big && b < p.n_big_wgs + p.n_mid_wgs;
   const long long after_big = p.n_big_wgs * p.groups_per_wg, after_mid = after_big + p.n_mid_wgs * p.mid_groups_per_wg;
+  StreamSpan s;
   s.epw = big ? p.groups_per_wg : mid ? p.mid_groups_per_wg : p.tail_groups_per_wg;
   s.g0 = big ? b * p.groups_per_wg
              : mid ? after_big + (b - p.n_big_wgs) * p.mid_groups_per_wg
                    : after_mid + (b - p.n_big_wgs - p.n_mid_wgs) * p.tail_groups_per_wg;
   s.n_local = (int)((n_groups - s.g0) < s.epw ? (n_groups - s.g0) : s.epw);
   return s;
-}
-
-// The relay between the runs of one epoch group (SenseParams::n_relay_groups).  A run that is not the group's last stores its
-// accumulator registers and raises the group's count of finished runs; the next run waits for that count, then starts from those
-// registers.  The two workgroups may sit on different XCDs, whose L2s do not snoop each other: every access of the relay is made at
-// agent scope (sc1: stores written through to the memory side, loads served from there), ordered by s_waitcnt and the workgroup
-// barrier — not by release / acquire fences, which on this part write back and invalidate a whole L2 (measured: 90 ns per relay
-// workgroup, serialised over the chip).  Roles are taken by ticket in the order the workgroups start, so a run's predecessor has
-// always started before it.
-constexpr int kAuxAgent = 16 | 2;   // sc1 nt: agent scope, streamed (no dirty lines left for the end-of-kernel write-back)
-// the thread index rebuilt from the wave number (a scalar) and the lane: threadIdx.x would otherwise sit in a vector register (or a
-// scratch slot) across the frame loop for the sake of one run's end
-template <class C>
-CRN_DEV int relay_tid(const FrameCtx<C> &c) {
-  return c.wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-template <class C>
-CRN_DEV void relay_pass_on(const FrameCtx<C> &c, const SenseParams &p, long long ri, int seg) {
-  const int tid = relay_tid(c);
-  // through a buffer resource: one 32-bit lane offset and a scalar offset per register (64-bit lane addresses would be held in
-  // vector registers across the frame loop)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.relay_acc + ri * (16 * 256), 0, 16 * 256 * 4, 0x00020000);
-  constexpr unsigned MASK = acc_mask<C>();   // the registers this kernel accumulates into
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-    if (((MASK >> r) & 1u) != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c.acc[r]), rs, tid * 4, r * 1024, kAuxAgent);
-  __builtin_amdgcn_s_waitcnt(0);   // this thread's stores have been acknowledged
-  __syncthreads();                 // ... and every thread's
-  if (tid == 0) {
-    unsigned done;   // formed here: as a loop invariant the compiler keeps it in a vector register (a scratch slot) across the frame loop
-    asm volatile("v_mov_b32 %0, %1" : "=v"(done) : "s"(seg + 1));
-    __hip_atomic_store(p.relay_ctl + 16 + ri, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-template <class C>
-CRN_DEV void relay_take_over(FrameCtx<C> &c, const SenseParams &p, long long ri, int seg) {
-  const int tid = relay_tid(c);
-  if (tid == 0) {
-    while (__hip_atomic_load(p.relay_ctl + 16 + ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)seg) __builtin_amdgcn_s_sleep(8);
-    if (seg + 1 == p.relay_segments) __hip_atomic_store(p.relay_ctl + 16 + ri, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-  }
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.relay_acc + ri * (16 * 256), 0, 16 * 256 * 4, 0x00020000);
-  constexpr unsigned MASK = acc_mask<C>();
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-    if (((MASK >> r) & 1u) != 0) c.acc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, r * 1024, kAuxAgent));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -149,24 +95,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   if constexpr (C::TW2LDS) {
     if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
   }
-  // A relay role (see relay_pass_on) is a ticket: run = ticket / n_relay_groups, group = ticket % n_relay_groups, so every run's
-  // predecessor holds a lower ticket and has started.  The last ticket of a launch leaves the counter at 0 for the next one (launches
-  // that share a relay buffer follow each other on one stream).  Word 0 of the exchange buffer is free until the first frame.
-  const bool relay_wg = (long long)blockIdx.x >= p.first_relay_wg;   // uniform; never true outside the plain streaming path
-  if (relay_wg && tid == 0) {
-    const unsigned tk = __hip_atomic_fetch_add(p.relay_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk + 1 == (unsigned)(p.n_relay_groups * p.relay_segments)) __hip_atomic_store(p.relay_ctl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *reinterpret_cast<unsigned *>(lds) = tk;
-  }
   __syncthreads();
-  int relay_run = -1;
-  long long relay_group = 0;
-  if (relay_wg) {
-    const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const unsigned *>(lds));
-    __syncthreads();   // before the first exchange overwrites the word
-    relay_run = (int)(tk / (unsigned)p.n_relay_groups);
-    relay_group = (long long)(tk % (unsigned)p.n_relay_groups);
-  }
   if constexpr (!C::TW2LDS) {
 #pragma unroll
     for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
@@ -336,29 +265,20 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       // 1.4 ms kernel).
       const StreamSpan sp = stream_span<R3>(p);
       const int epw = sp.epw, n_local = sp.n_local;
-      const long long g0 = sp.g0 + relay_group;
+      const long long g0 = sp.g0;
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
       const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
-      // a relay run takes frames [K run / S, K (run + 1) / S) of its group; every other workgroup all K of each of its groups
-      int j = 0, f = 0, f_end = K;
-      bool pass_on = false;
-      if (relay_run >= 0) {
-        f = K * relay_run / p.relay_segments;
-        f_end = K * (relay_run + 1) / p.relay_segments;
-        pass_on = relay_run + 1 < p.relay_segments;
-      }
-      load_frame<R3, NT, SC>(ua, rs, voff, (unsigned)f * fbytes, C::FULL ? G::N : c.L);
-      if (relay_run > 0) relay_take_over<C>(c, p, relay_group, relay_run);
+      load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
+      int j = 0, f = 0;
 #define CRN_STREAM_STEP(CUR, NXT)                                                                   \
       {                                                                                             \
-        const bool last = f + 1 == f_end;                                                           \
+        const bool last = f + 1 == K;                                                               \
         const int j_n = last ? j + 1 : j;                                                           \
         const int f_n = last ? 0 : f + 1;                                                           \
         const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
         frame_compute<C, true>(CUR, c, f, &NXT, rs, voff, soff_n);                                   \
         if (last) {                                                                                 \
-          if (pass_on) relay_pass_on<C>(c, p, relay_group, relay_run);                              \
-          else epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                          \
+          epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                               \
         }                                                                                           \
         j = j_n;                                                                                    \
         f = f_n;                                                                                    \
@@ -406,19 +326,13 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 template <class C>
 static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   using G = Geo<C::R3>;
+  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
   // Welch (hop = N/2) streams when the epochs are dense (see sense_kernel)
   const bool welch = C::WIN && p.frame_stride * 2 == G::N;
   const bool welch_stream = welch && p.epoch_stride == (long long)p.K * (G::N / 2);
   const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
                      (!welch || welch_stream);
   SenseParams q = p;
-  // the relayed end belongs to the plain streaming path (not to the Welch stream, whose workgroups carry half-frames across epochs)
-  if (!multi || welch || q.relay_ctl == nullptr || q.relay_acc == nullptr || q.relay_segments < 2 || q.relay_segments > q.K ||
-      q.n_relay_groups < 0)
-    q.n_relay_groups = 0;
-  // the groups ahead of the relayed end
-  const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS - q.n_relay_groups;
-  if (n_groups < 0) return hipErrorInvalidValue;
   unsigned grid;
   if (multi) {
     // n_big_wgs workgroups of groups_per_wg groups, then workgroups of tail_groups_per_wg over the remaining groups
@@ -428,14 +342,12 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
     if (q.n_mid_wgs > 0 && q.n_big_wgs * q.groups_per_wg + q.n_mid_wgs * q.mid_groups_per_wg > n_groups)
       q.n_mid_wgs = (n_groups - q.n_big_wgs * q.groups_per_wg) / q.mid_groups_per_wg;
     const long long rest = n_groups - q.n_big_wgs * q.groups_per_wg - q.n_mid_wgs * (q.n_mid_wgs > 0 ? q.mid_groups_per_wg : 0);
-    q.first_relay_wg = q.n_big_wgs + q.n_mid_wgs + (rest + q.tail_groups_per_wg - 1) / q.tail_groups_per_wg;
-    grid = (unsigned)(q.first_relay_wg + q.n_relay_groups * q.relay_segments);
+    grid = (unsigned)(q.n_big_wgs + q.n_mid_wgs + (rest + q.tail_groups_per_wg - 1) / q.tail_groups_per_wg);
   } else {
     q.n_big_wgs = 0;
     q.n_mid_wgs = 0;
     q.tail_groups_per_wg = 1;
     grid = (unsigned)n_groups;
-    q.first_relay_wg = n_groups;
   }
   const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
   if (grid == 0) return hipSuccess;

@@ -24,7 +24,7 @@ iq = torch.zeros(cs.samples_needed(cfg, E_max) * 2, dtype=torch.float32, device=
 stream = torch.cuda.current_stream().cuda_stream
 s.synth_fill_device(iq.data_ptr(), E_max, spe, seed=1, stream=stream)
 s.set_variant(17)
-if os.environ.get("CRN_TIMELINE_GEOMETRY"):   # e.g. "200,616,702": geometry codes of crn_sense_set_variant, applied in order
+if os.environ.get("CRN_TIMELINE_GEOMETRY"):   # e.g. "208,104": geometry codes of crn_sense_set_variant, applied in order
     for code in os.environ["CRN_TIMELINE_GEOMETRY"].split(","):
         s.set_variant(int(code))
     print("geometry codes:", os.environ["CRN_TIMELINE_GEOMETRY"])
