@@ -1032,3 +1032,48 @@ def test_two_handles_on_two_threads(built):
         assert np.allclose(got["features"], want["features"], rtol=1e-5, atol=0), i
         assert np.array_equal(got["decision"], want["decision"]), i
         assert np.array_equal(got["occupancy"], want["occupancy"]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["energy4096", "ref512", "welch4096"])
+def test_one_handle_launching_on_two_streams(built, cfg_name):
+    """Batches are independent (no state crosses epochs: CE_Predictive_Node.cpp:287-288 resets everything at the close), so a
+    caller with a queue of batches alternates two streams and the launches overlap (bench.py's `cfgH_2GiB_batch_two_streams`,
+    DESIGN.md §6).  One handle, two streams, different inputs in flight at once: every launch gets its own batch's results."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg, L = {"energy4096": (cs.cfg_energy_scaled(4096, 4.0), 4096), "ref512": (cs.cfg_reference(), 364),
+              "welch4096": (cs.cfg_welch(4096, 8, 64), 4096)}[cfg_name]
+    if cfg.n_bands == 64:
+        for b in range(64):
+            cfg.thresh[b] = 1e-3
+    n_epochs = 1100 * 4096 // cfg.fft_len   # a little over one round of the workgroup slots: the next launch starts in this one's drain
+    s = cs.Sensor(cfg)
+    batches = []
+    for k in range(2):
+        iq, _ = signals.make_epochs(cfg, n_epochs, seed=40 + k, L=L)
+        batches.append((torch.from_numpy(iq).to(dev), orc.run(cfg, iq, n_epochs, L=L)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = []
+    for i in range(8):
+        t = [torch.zeros(n_epochs, cfg.n_bands, device=dev), torch.zeros(n_epochs, 3, dtype=torch.float64, device=dev),
+             torch.zeros(n_epochs, dtype=torch.int32, device=dev), torch.zeros(n_epochs, cfg.n_bands, dtype=torch.uint8, device=dev)]
+        outs.append(t)
+    torch.cuda.synchronize()
+    for i in range(8):
+        t = outs[i]
+        s.run_device(batches[i & 1][0].data_ptr(), n_epochs, L,
+                     {"features": t[0].data_ptr(), "ann_out": t[1].data_ptr(), "decision": t[2].data_ptr(), "occupancy": t[3].data_ptr(),
+                      "spectrum": 0}, stream=streams[(i >> 1) & 1].cuda_stream)   # both inputs on both streams
+    torch.cuda.synchronize()
+    for i in range(8):
+        want = batches[i & 1][1]
+        feats = outs[i][0].cpu().numpy()
+        dec = outs[i][2].cpu().numpy()
+        occ = outs[i][3].cpu().numpy()
+        assert np.allclose(feats, want["features"], rtol=1e-5, atol=0), i
+        assert np.array_equal(dec, want["decision"]), i
+        assert np.array_equal(occ, want["occupancy"]), i
+        if i >= 2:   # the same input through the same kernel: bit-identical whatever ran beside it
+            assert all(torch.equal(a, b) for a, b in zip(outs[i], outs[i - 2])), i
+    s.close()
