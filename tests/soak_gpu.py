@@ -11,8 +11,9 @@ _os.environ.setdefault("CRN_SENSE_AB", "1")   # measurement variants: libcrnsens
 import crnsense as cs, oracle_py as orc, signals
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # python tests/soak_gpu.py <n> <first seed>: seeds first .. first + n - 1
 bad = 0
-for seed in range(n_seeds):
+for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(50000 + seed)
     n = int(rng.choice([512, 1024, 2048, 4096]))
     ref_plan = rng.random() < 0.35
@@ -108,5 +109,5 @@ for seed in range(n_seeds):
         bad += 1
         print("MISMATCH seed", seed, dict(n=n, mode=cfg.mode, K=cfg.frames_per_epoch, win=cfg.window, L=L, variant=variant,
                                          spec=want_spec, epochs=n_epochs, ref_plan=ref_plan, welch=welch, aligned=aligned, nb=cfg.n_bands, decide=cfg.decide, epw=epw, tail=tail, stride=stride))
-print(f"soak: {n_seeds} configurations ({globals().get('n_wire', 0)} of them also through the wire-format path, compared bit for bit), {bad} mismatches")
+print(f"soak: {n_seeds} configurations, seeds {first} .. {first + n_seeds - 1} ({globals().get('n_wire', 0)} of them also through the wire-format path, compared bit for bit), {bad} mismatches")
 sys.exit(1 if bad else 0)
