@@ -525,9 +525,9 @@ CRN_API int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, i
 
 /* Which form of the sensing kernel a handle launches (set before running).  The shipped library carries the forms that are sensing
  * results: 0 (= 13) the default; 2 without the pruning of pass 3 to the registers the reference channel plan reaches (what any band
- * table outside that plan runs anyway); 23 every twiddle in registers at three workgroups per CU.  100 + n / 200 + n / 300 + n /
- * 400 + n / 500 + n override the launch geometry (epochs per big workgroup; x 256 epochs in tail workgroups; epochs per tail
- * workgroup; epochs per middle-tier workgroup; x 256 epochs in the middle tier) and change no result.  Everything else — other
+ * table outside that plan runs anyway); 23 every twiddle in registers at three workgroups per CU.  100 + n / 200 + n / 300 + n
+ * override the launch geometry (epochs per big workgroup; x 256 epochs in tail workgroups; epochs per tail workgroup) and change
+ * no result.  Everything else — other
  * schedules, ablations that compute nothing useful, a trace build — is a measurement variant compiled only into libcrnsense_ab.so
  * (make -C csrc ab) and refused here with CRN_ERR_ARG. */
 CRN_API int crn_sense_set_variant(crn_handle *h, int32_t variant);

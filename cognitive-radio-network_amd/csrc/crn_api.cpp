@@ -35,8 +35,6 @@ struct crn_handle {
   int groups_per_wg = 0;        // 0 = automatic
   int64_t tail_groups = -1;     // < 0 = automatic; epoch groups handed to the short tail workgroups at the end
   int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
-  int mid_groups_per_wg = -1;   // < 0 = automatic; epoch groups per middle-tier workgroup (0: no middle tier)
-  int64_t mid_groups = -1;      // < 0 = automatic; epoch groups handed to the middle tier
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   std::atomic<int> n_rings{0};  // ingest rings created on this handle (they size their result buffers for cfg.n_bands)
@@ -365,14 +363,6 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
     h->tail_groups_per_wg = variant - 300;
     return CRN_OK;
   }
-  if (variant >= 400 && variant <= 464) {  // A/B: 400 + n = n epoch groups per middle-tier workgroup (400 = no middle tier)
-    h->mid_groups_per_wg = variant - 400;
-    return CRN_OK;
-  }
-  if (variant >= 500 && variant <= 564) {  // A/B: 500 + n = n x 256 epoch groups in the middle tier
-    h->mid_groups = (int64_t)(variant - 500) * 256;
-    return CRN_OK;
-  }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
   if (!crn::sense_variant_available(variant))
     return crn::fail(CRN_ERR_ARG, "variant " + std::to_string(variant) + " is a measurement variant: it is compiled into libcrnsense_ab.so "
@@ -543,14 +533,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     if (h->tail_groups >= 0) tail = h->tail_groups;
     if (tail > n_groups / 4) tail = n_groups / 4;
     p.tail_groups_per_wg = (int)(h->tail_groups_per_wg > 0 ? h->tail_groups_per_wg : tail_epw);
-    int64_t mid = 0, mid_epw = 0;     // middle tier: none by default
-    if (h->mid_groups_per_wg >= 0) mid_epw = h->mid_groups_per_wg;
-    if (h->mid_groups >= 0) mid = h->mid_groups;
-    if (mid_epw < 1) mid = 0;
-    if (mid > (n_groups - tail) / 2) mid = (n_groups - tail) / 2;
-    p.mid_groups_per_wg = (int)mid_epw;
-    p.n_mid_wgs = mid_epw > 0 ? mid / mid_epw : 0;
-    p.n_big_wgs = (n_groups - tail - p.n_mid_wgs * mid_epw) / p.groups_per_wg;
+    p.n_big_wgs = (n_groups - tail) / p.groups_per_wg;
   }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;

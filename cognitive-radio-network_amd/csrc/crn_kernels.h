@@ -24,8 +24,6 @@ struct SenseParams {
   int groups_per_wg;       // consecutive epoch groups one workgroup streams through (>= 1)
   long long n_big_wgs;     // workgroups [0, n_big_wgs) take groups_per_wg groups each; the ones after them
                            // tail_groups_per_wg each (they are dispatched last: the end of the kernel drains in small steps)
-  long long n_mid_wgs;     // workgroups [n_big_wgs, n_big_wgs + n_mid_wgs) take mid_groups_per_wg groups each (0: no middle tier)
-  int mid_groups_per_wg;
   int tail_groups_per_wg;  // >= 1 (1 for the plain kernels; the Welch stream, which re-reads one half-frame per workgroup span,
                            // keeps its tail workgroups longer)
   // tables (device, built at crn_sense_create)

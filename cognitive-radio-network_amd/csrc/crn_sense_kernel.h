@@ -27,15 +27,12 @@ template <int R3>
 CRN_DEV StreamSpan stream_span(const SenseParams &p) {
   using G = Geo<R3>;
   const long long n_groups = (p.n_epochs + G::GROUPS - 1) / G::GROUPS;
-  // three tiers in dispatch order: big spans, then (optionally) middle ones, then the short tail
+  // two tiers in dispatch order: big spans, then the short tail
   const long long b = (long long)blockIdx.x;
-  const bool big = b < p.n_big_wgs, mid = !big && b < p.n_big_wgs + p.n_mid_wgs;
-  const long long after_big = p.n_big_wgs * p.groups_per_wg, after_mid = after_big + p.n_mid_wgs * p.mid_groups_per_wg;
+  const bool big = b < p.n_big_wgs;
   StreamSpan s;
-  s.epw = big ? p.groups_per_wg : mid ? p.mid_groups_per_wg : p.tail_groups_per_wg;
-  s.g0 = big ? b * p.groups_per_wg
-             : mid ? after_big + (b - p.n_big_wgs) * p.mid_groups_per_wg
-                   : after_mid + (b - p.n_big_wgs - p.n_mid_wgs) * p.tail_groups_per_wg;
+  s.epw = big ? p.groups_per_wg : p.tail_groups_per_wg;
+  s.g0 = big ? b * p.groups_per_wg : p.n_big_wgs * p.groups_per_wg + (b - p.n_big_wgs) * p.tail_groups_per_wg;
   s.n_local = (int)((n_groups - s.g0) < s.epw ? (n_groups - s.g0) : s.epw);
   return s;
 }
@@ -338,14 +335,10 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
     // n_big_wgs workgroups of groups_per_wg groups, then workgroups of tail_groups_per_wg over the remaining groups
     if (q.tail_groups_per_wg < 1) q.tail_groups_per_wg = 1;
     if (q.n_big_wgs * q.groups_per_wg > n_groups) q.n_big_wgs = n_groups / q.groups_per_wg;
-    if (q.mid_groups_per_wg < 1 || q.n_mid_wgs < 0) q.n_mid_wgs = 0;
-    if (q.n_mid_wgs > 0 && q.n_big_wgs * q.groups_per_wg + q.n_mid_wgs * q.mid_groups_per_wg > n_groups)
-      q.n_mid_wgs = (n_groups - q.n_big_wgs * q.groups_per_wg) / q.mid_groups_per_wg;
-    const long long rest = n_groups - q.n_big_wgs * q.groups_per_wg - q.n_mid_wgs * (q.n_mid_wgs > 0 ? q.mid_groups_per_wg : 0);
-    grid = (unsigned)(q.n_big_wgs + q.n_mid_wgs + (rest + q.tail_groups_per_wg - 1) / q.tail_groups_per_wg);
+    const long long rest = n_groups - q.n_big_wgs * q.groups_per_wg;
+    grid = (unsigned)(q.n_big_wgs + (rest + q.tail_groups_per_wg - 1) / q.tail_groups_per_wg);
   } else {
     q.n_big_wgs = 0;
-    q.n_mid_wgs = 0;
     q.tail_groups_per_wg = 1;
     grid = (unsigned)n_groups;
   }
