@@ -69,8 +69,13 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 #ifdef CRN_AB_VARIANTS
   if constexpr ((C::OPT & kTrace) != 0) {
     // workgroup start on the wall clock, behind the [epoch][3] close stamps (the caller's buffer holds 4 words per epoch)
-    if (tid == 0 && p.ann_out != nullptr)
-      reinterpret_cast<unsigned long long *>(p.ann_out)[p.n_epochs * 3 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    // ... and, half a buffer further, where it runs: HW_ID (wave / SIMD / CU / SE) in the low word, XCC_ID in the high one
+    if (tid == 0 && p.ann_out != nullptr) {
+      unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
+      tr[p.n_epochs * 3 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      tr[p.n_epochs * 3 + p.n_epochs / 2 + blockIdx.x] =
+          (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
   }
 #endif
   const int K = p.K;
