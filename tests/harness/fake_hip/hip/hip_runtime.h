@@ -60,4 +60,22 @@ inline hipError_t hipEventSynchronize(hipEvent_t e) {
   while (hipEventQuery(e) != hipSuccess) std::this_thread::sleep_for(std::chrono::microseconds(20));
   return hipSuccess;
 }
+
+// What csrc/crn_api.cpp needs beyond the ring's calls (tests/harness/api_unit.cpp: table building and launch geometry on the host).
+// The "device" has g_fake_hip_cus compute units; kernels are the test's own stand-ins for the launch_* functions.
+#define HIP_VERSION_MAJOR 7
+#define HIP_VERSION_MINOR 2
+#define HIP_VERSION_PATCH 0
+#define HIP_VERSION (HIP_VERSION_MAJOR * 10000000 + HIP_VERSION_MINOR * 100000 + HIP_VERSION_PATCH)
+struct float2 { float x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n); }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+inline int g_fake_hip_cus = 256;
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int *v, int attr, int) { *v = attr == hipDeviceAttributeMultiprocessorCount ? g_fake_hip_cus : 0; return hipSuccess; }
+inline hipError_t hipRuntimeGetVersion(int *v) { *v = HIP_VERSION; return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { fake_hip_note(true); std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->ready_at_ns.load() - a->ready_at_ns.load()) * 1e-6); return hipSuccess; }
 #endif

@@ -46,6 +46,20 @@ def test_butterfly_algebra_on_the_host(built):
     assert out.returncode == 0 and "butterfly_unit: ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_api_host_logic_tables_and_launch_geometry(built):
+    """tests/harness/api_unit.cpp: csrc/crn_api.cpp + crn_cfg.cpp as they are, over the host-only HIP stand-in (device memory is host
+    memory; the launch functions record the parameter block): the twiddle tables against long-double values, the Hann table and its
+    w[n] + w[n + N/2] = 1 symmetry, the packed band table and its row entries rebuilt into the plan bin by bin, the accumulator mask
+    against the layout rule, every epoch group handed to exactly one workgroup for 5 CU counts x 4 sizes x 4 K x 21 batch sizes (and
+    the Welch stream's spans), argument refusals before any launch, live threshold / network / band-plan updates, the shipped
+    variant policy, counters.  AddressSanitizer + UBSan build."""
+    exe = os.path.join(HARNESS, "api_unit")
+    subprocess.check_call(["make", "-C", HARNESS, exe], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "api_unit: tables" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[:3000]
+
+
 def test_ring_and_engine_under_address_and_ub_sanitizers(built):
     """The same two programs built with -fsanitize=address,undefined (they cannot share a build with ThreadSanitizer): the pinned
     buffers' slot arithmetic, the carry-over copies of open epochs, the byte-sized layout of the wire-format ring."""
