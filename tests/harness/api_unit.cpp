@@ -24,9 +24,27 @@ namespace {
 crn::SenseParams g_last;
 int g_last_fft = 0, g_last_variant = -1, g_launches = 0;
 bool g_last_mag = false, g_last_win = false, g_last_sc16 = false;
+bool g_write_pattern = false;
+float g_iq_first = 0, g_iq_last = 0;
 }  // namespace
 namespace crn {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t, bool sc16) {
+  if (g_write_pattern) {
+    // what a launch reads and writes, touched at its ends (under AddressSanitizer a slab one byte short is a report) and filled
+    // with values the caller can recognise after the copies back
+    const float2 first = p.iq[0], last = p.iq[p.total_samples - 1];
+    g_iq_first = first.x;
+    g_iq_last = last.y;
+    for (long long e = 0; e < p.n_epochs; e++) {
+      for (int b = 0; b < p.n_bands; b++) {
+        if (p.features) p.features[e * p.n_bands + b] = (float)(e * 100 + b);
+        if (p.occupancy) p.occupancy[e * p.n_bands + b] = (uint8_t)((e + b) & 1);
+      }
+      if (p.ann_out) for (int k = 0; k < 3; k++) p.ann_out[e * 3 + k] = (double)e + 0.25 * k;
+      if (p.decision) p.decision[e] = (int32_t)(e % 4);
+      if (p.spectrum) for (int k = 0; k < fft_len; k++) p.spectrum[e * fft_len + k] = (float)(e + k);
+    }
+  }
   g_last = p;
   g_last_fft = fft_len;
   g_last_mag = mag;
@@ -333,6 +351,73 @@ static void test_arguments_and_counters() {
   REQUIRE(crn_build_info(&built, &runtime) == CRN_OK && built == runtime && built == HIP_VERSION);
 }
 
+// crn_sense_run_host: the staging slabs (pinned in-place form for a decision's worth of samples, device scratch + pinned results
+// otherwise) hold exactly what the launch touches, and every output comes back to the caller's arrays
+static void run_host_case(crn_cfg cfg, int64_t E, int L, bool want_spectrum) {
+  crn_handle *h = nullptr;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  const int N = cfg.fft_len, K = cfg.frames_per_epoch;
+  const bool overlapped = cfg.hop != N;
+  const int64_t n_samples = overlapped ? (E * K - 1) * (int64_t)cfg.hop + N : E * K * (int64_t)L;
+  std::vector<float> iq((size_t)n_samples * 2);
+  for (size_t i = 0; i < iq.size(); i++) iq[i] = (float)(i % 8191);
+  std::vector<float> feat((size_t)E * cfg.n_bands, -1.f), spec(want_spectrum ? (size_t)E * N : 0, -1.f);
+  std::vector<double> ann((size_t)E * 3, -1.0);
+  std::vector<int32_t> dec((size_t)E, -1);
+  std::vector<uint8_t> occ((size_t)E * cfg.n_bands, 9);
+  crn_out o{feat.data(), ann.data(), dec.data(), occ.data(), want_spectrum ? spec.data() : nullptr};
+  g_write_pattern = true;
+  const int rc = crn_sense_run_host(h, iq.data(), E, L, 0, &o);
+  g_write_pattern = false;
+  if (rc != CRN_OK) std::fprintf(stderr, "api_unit: run_host failed: %s\n", crn_last_error());
+  REQUIRE(rc == CRN_OK);
+  REQUIRE(g_last.total_samples == n_samples);
+  REQUIRE(g_iq_first == iq[0] && g_iq_last == iq[iq.size() - 1]);   // the launch saw the caller's samples, first to last
+  bool ok = true;
+  for (int64_t e = 0; e < E && ok; e++) {
+    for (int b = 0; b < cfg.n_bands; b++) ok = ok && feat[e * cfg.n_bands + b] == (float)(e * 100 + b) && occ[e * cfg.n_bands + b] == (uint8_t)((e + b) & 1);
+    ok = ok && dec[e] == (int32_t)(e % 4);
+    if (cfg.decide == CRN_DECIDE_ANN) for (int k = 0; k < 3; k++) ok = ok && ann[e * 3 + k] == (double)e + 0.25 * k;
+    else ok = ok && ann[e * 3] == -1.0;   // not the network's mode: left alone
+    if (want_spectrum) ok = ok && spec[e * N] == (float)e && spec[e * N + N - 1] == (float)(e + N - 1);
+  }
+  REQUIRE(ok);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+}
+
+static void test_run_host() {
+  crn_cfg cfg;
+  REQUIRE(crn_cfg_reference(&cfg) == CRN_OK);
+  for (int64_t E : {1, 2, 12, 300, 5000}) {   // in-place pinned form for the small ones, scratch + pinned results for the others
+    run_host_case(cfg, E, 364, false);
+    run_host_case(cfg, E, 512, false);
+  }
+  run_host_case(cfg, 1, 512, true);
+  run_host_case(cfg, 77, 100, true);
+  REQUIRE(crn_cfg_energy_scaled(&cfg, 4096, 4.0f) == CRN_OK);
+  for (int64_t E : {1, 3, 200}) run_host_case(cfg, E, 4096, E == 3);
+  REQUIRE(crn_cfg_welch(&cfg, 4096, 8, 64) == CRN_OK);
+  for (int b = 0; b < 64; b++) cfg.thresh[b] = 1.0f;
+  for (int64_t E : {1, 5, 40}) run_host_case(cfg, E, 4096, false);
+  REQUIRE(crn_cfg_welch_scaled(&cfg, 1024, 6, 4.0f) == CRN_OK);
+  run_host_case(cfg, 9, 1024, true);
+  // a handle re-used with growing and shrinking batches keeps its slabs consistent
+  REQUIRE(crn_cfg_reference(&cfg) == CRN_OK);
+  crn_handle *h = nullptr;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_reserve_host(h, 64, 1) == CRN_OK);
+  g_write_pattern = true;
+  for (int64_t E : {1, 500, 3, 2000, 1, 64}) {
+    std::vector<float> iq((size_t)E * 3640 * 2, 1.f), feat((size_t)E * 4);
+    std::vector<int32_t> dec((size_t)E);
+    crn_out o{feat.data(), nullptr, dec.data(), nullptr, nullptr};
+    REQUIRE(crn_sense_run_host(h, iq.data(), E, 364, 0, &o) == CRN_OK);
+    REQUIRE(feat[(size_t)(E - 1) * 4 + 3] == (float)((E - 1) * 100 + 3) && dec[(size_t)E - 1] == (int32_t)((E - 1) % 4));
+  }
+  g_write_pattern = false;
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+}
+
 int main() {
   for (int N : {512, 1024, 2048, 4096}) {
     test_tables(N, true);
@@ -341,10 +426,11 @@ int main() {
   test_windows();
   test_geometry();
   test_arguments_and_counters();
+  test_run_host();
   if (g_failed) {
     std::fprintf(stderr, "api_unit: %d check(s) failed\n", g_failed);
     return 1;
   }
-  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates: ok\n");
+  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates, host-buffer staging: ok\n");
   return 0;
 }
