@@ -26,6 +26,12 @@ int g_last_fft = 0, g_last_variant = -1, g_launches = 0;
 bool g_last_mag = false, g_last_win = false, g_last_sc16 = false;
 bool g_write_pattern = false;
 float g_iq_first = 0, g_iq_last = 0;
+crn::FftParams g_fft;
+crn::MonitorParams g_mon;
+crn::SynthParams g_synth;
+int g_fft_len = 0, g_synth_launches = 0, g_pattern_launches = 0;
+long long g_pack_n = 0;
+float g_pack_scale = 0;
 }  // namespace
 namespace crn {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t, bool sc16) {
@@ -60,12 +66,18 @@ unsigned sense_ref_acc_mask(int fft_len) { return fft_len == 512 ? 0x85e1u : fft
 bool sense_variant_available(int v) { return v == 0 || v == 13 || v == 2 || v == 23; }   // the shipped library's set
 void sense_variant(int, int, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) { *nbuf = 1; *prefetch = 1; *nt = 1; *tw2lds = 0; *pk = 1; }
 void sense_geometry(int fft_len, int, int *threads, int *lds_bytes, int *epochs_per_block) { *threads = 256; *lds_bytes = 0; *epochs_per_block = 256 / (fft_len / 16); }
-hipError_t launch_fft(const FftParams &, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_monitor(const MonitorParams &, hipStream_t) { return hipSuccess; }
-hipError_t launch_noise_floor(const float *, int, int, float *, hipStream_t) { return hipSuccess; }
-hipError_t launch_synth(const SynthParams &, hipStream_t) { return hipSuccess; }
-hipError_t launch_pack_sc16(const float *, long long, short *, float, hipStream_t) { return hipSuccess; }
-hipError_t launch_pu_pattern(const SynthParams &, hipStream_t) { return hipSuccess; }
+hipError_t launch_fft(const FftParams &p, int fft_len, hipStream_t) { g_fft = p; g_fft_len = fft_len; return hipSuccess; }
+hipError_t launch_monitor(const MonitorParams &p, hipStream_t) { g_mon = p; return hipSuccess; }
+hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t) {
+  // touches what the kernel touches: the features it was given and the result word behind kNoiseFloorMaxEpochs medians
+  float sum = 0;
+  for (long long i = 0; i < (long long)n_epochs * nb; i++) sum += feat[i];
+  scratch[kNoiseFloorMaxEpochs] = sum;
+  return hipSuccess;
+}
+hipError_t launch_synth(const SynthParams &p, hipStream_t) { g_synth = p; g_synth_launches++; return hipSuccess; }
+hipError_t launch_pack_sc16(const float *, long long n, short *, float full_scale, hipStream_t) { g_pack_n = n; g_pack_scale = full_scale; return hipSuccess; }
+hipError_t launch_pu_pattern(const SynthParams &, hipStream_t) { g_pattern_launches++; return hipSuccess; }
 }  // namespace crn
 
 // ---- checks ---------------------------------------------------------------------------------------------------------
@@ -418,6 +430,75 @@ static void test_run_host() {
   REQUIRE(crn_sense_destroy(h) == CRN_OK);
 }
 
+// the calls either side of the sensing launch: what they derive from the handle and what they refuse
+static void test_side_paths() {
+  crn_cfg cfg;
+  REQUIRE(crn_cfg_reference(&cfg) == CRN_OK);
+  crn_handle *h = nullptr;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  static float buf[2048], state[512];
+  // generator: the band lists the kernel draws tones from, and twice the signed centre of every band (bins >= N/2 are negative
+  // frequencies; CH1 = bins -16..-2 and 0..15 of CE_Predictive_Node.cpp:173-179)
+  int32_t truth[8];
+  REQUIRE(crn_synth_fill_device(h, buf, 8, 128, 7, 1e-6f, 0.02f, 8, truth, nullptr) == CRN_OK);
+  REQUIRE(g_synth.n_epochs == 8 && g_synth.samples_per_epoch == 128 && g_synth.fft_len == 512 && g_synth.truth == truth);
+  REQUIRE(g_synth.active_band0 == 1 && g_synth.n_active == 3);                 // band 0 (the noise-floor band) is never driven
+  REQUIRE(std::fabs(g_synth.noise_sigma - std::sqrt(0.5e-6f)) < 1e-9f && std::fabs(g_synth.tone_amp - 0.02f / std::sqrt(8.f)) < 1e-9f);
+  const int *bb = g_synth.band_bins_begin, *bins = g_synth.band_bins, *c2 = g_synth.band_c2;
+  REQUIRE(bb[0] == 0 && bb[1] == 10 && bb[2] == 41 && bb[3] == 71 && bb[4] == 104);   // NF 10, CH1 31, CH2 30, CH3 33 bins (.cpp:173-191)
+  REQUIRE(bins[0] == 300 && bins[9] == 309 && bins[10] == 0 && bins[25] == 15 && bins[26] == 496 && bins[40] == 510 && bins[41] == 55 && bins[103] == 221);
+  REQUIRE(c2[0] == (300 - 512) + (309 - 512) && c2[1] == -16 + 15 && c2[2] == 55 + 84 && c2[3] == 189 + 221);
+  crn_synth_cfg sc{};
+  sc.seed = 1; sc.noise_power = 1e-6f; sc.signal_rms = 0.02f; sc.tones_per_band = 8; sc.n_streams = 2; sc.adc_bits = 16;
+  sc.pu_model = CRN_PU_MARKOV_INTENDED; sc.signal_kind = CRN_SIG_OFDM;
+  const int pat = g_pattern_launches;
+  REQUIRE(crn_synth_fill_device_ex(h, &sc, buf, 8, 128, truth, nullptr) == CRN_OK);
+  REQUIRE(g_pattern_launches == pat + 1 && g_synth.epochs_per_stream == 4 && g_synth.adc_scale == 32768.f && g_synth.signal_kind == CRN_SIG_OFDM);
+  REQUIRE(crn_synth_fill_device_ex(h, &sc, buf, 8, 128, nullptr, nullptr) == CRN_ERR_ARG);   // Markov models keep their state in d_truth
+  REQUIRE(crn_synth_fill_device_ex(h, &sc, buf, 7, 128, truth, nullptr) == CRN_ERR_ARG);     // streams must divide the epochs
+  sc.adc_bits = 1;
+  REQUIRE(crn_synth_fill_device_ex(h, &sc, buf, 8, 128, truth, nullptr) == CRN_ERR_ARG);
+  sc.adc_bits = 0; sc.signal_kind = 99;
+  REQUIRE(crn_synth_fill_device_ex(h, &sc, buf, 8, 128, truth, nullptr) == CRN_ERR_ARG);
+  // the transform on its own
+  REQUIRE(crn_fft_forward_device(h, buf, 3, 364, 0, buf, nullptr) == CRN_OK);
+  REQUIRE(g_fft_len == 512 && g_fft.n_frames == 3 && g_fft.L == 364 && g_fft.frame_stride == 364 && g_fft.tw1 != nullptr && g_fft.tw2 != nullptr);
+  REQUIRE(crn_fft_forward_device(h, buf, 3, 513, 0, buf, nullptr) == CRN_ERR_ARG);
+  REQUIRE(crn_fft_forward_device(h, buf, -1, 512, 0, buf, nullptr) == CRN_ERR_ARG);
+  // display rows: the two normalisations (gr-qtgui's dB of |X|^2 / N^2, a PSD over the window's power)
+  REQUIRE(crn_monitor_rows_device(h, buf, 4, CRN_MONITOR_GNURADIO, 0.1f, 1, state, nullptr, buf, nullptr) == CRN_OK);
+  REQUIRE(g_mon.n == 512 && g_mon.db_domain == 1 && g_mon.first == 1 && std::fabs(g_mon.scale - 1.0f / (512.f * 512.f)) < 1e-12f);
+  REQUIRE(crn_monitor_rows_device(h, buf, 4, CRN_MONITOR_PSD, 1.0f, 0, state, buf, nullptr, nullptr) == CRN_OK);
+  REQUIRE(g_mon.db_domain == 0 && std::fabs(g_mon.scale - 1.0f / (512.f * 512.f)) < 1e-12f);   // rectangular window: power N
+  REQUIRE(crn_monitor_rows_device(h, buf, 4, CRN_MONITOR_PSD, 0.0f, 0, state, buf, nullptr, nullptr) == CRN_ERR_ARG);
+  REQUIRE(crn_monitor_rows_device(h, buf, 4, 7, 0.5f, 0, state, buf, nullptr, nullptr) == CRN_ERR_ARG);
+  // noise floor from host features: staged, measured, read back (the stand-in leaves the sum where the kernel leaves its estimate)
+  float feats[6 * 4], nf = -1.f;
+  for (int i = 0; i < 24; i++) feats[i] = 0.5f;
+  REQUIRE(crn_noise_floor_host(h, feats, 6, &nf) == CRN_OK && nf == 12.0f);
+  REQUIRE(crn_noise_floor_host(h, feats, 0, &nf) == CRN_ERR_ARG);
+  // wire format: full scale, alignment of int16 pairs
+  static int16_t wire[64];
+  REQUIRE(crn_sense_set_wire_full_scale(h, 8192.0) == CRN_OK && crn_sense_set_wire_full_scale(h, 0.5) == CRN_ERR_ARG);
+  REQUIRE(crn_pack_sc16_device(h, buf, 1000, wire, nullptr) == CRN_OK && g_pack_n == 1000 && g_pack_scale == 8192.f);
+  const crn_out o = any_outputs();
+  REQUIRE(crn_sense_run_device_sc16(h, wire, 3, 364, 0, &o, nullptr) == CRN_OK && g_last_sc16);
+  REQUIRE(std::fabs(g_last.wire_unscale - 1.0f / 8192.f) < 1e-12f);   // a sum of magnitudes unscales once, an energy twice
+  REQUIRE(crn_sense_run_device_sc16(h, wire + 1, 3, 364, 0, &o, nullptr) == CRN_ERR_ARG);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  REQUIRE(crn_cfg_energy_scaled(&cfg, 1024, 4.0f) == CRN_OK);
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device_sc16(h, wire, 1, 1024, 0, &o, nullptr) == CRN_OK && std::fabs(g_last.wire_unscale - 1.0f / (32768.f * 32768.f)) < 1e-18f);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  // a Hann monitor handle: the PSD normalisation uses the window's power (N x 3/8)
+  REQUIRE(crn_cfg_welch(&cfg, 4096, 8, 64) == CRN_OK);
+  for (int b = 0; b < 64; b++) cfg.thresh[b] = 1.0f;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_monitor_rows_device(h, buf, 1, CRN_MONITOR_PSD, 0.5f, 1, state, buf, nullptr, nullptr) == CRN_OK);
+  REQUIRE(std::fabs(g_mon.scale * (4096.0 * 4096.0 * 0.375) - 1.0) < 1e-6);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+}
+
 int main() {
   for (int N : {512, 1024, 2048, 4096}) {
     test_tables(N, true);
@@ -427,10 +508,11 @@ int main() {
   test_geometry();
   test_arguments_and_counters();
   test_run_host();
+  test_side_paths();
   if (g_failed) {
     std::fprintf(stderr, "api_unit: %d check(s) failed\n", g_failed);
     return 1;
   }
-  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates, host-buffer staging: ok\n");
+  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates, host-buffer staging, side paths: ok\n");
   return 0;
 }
