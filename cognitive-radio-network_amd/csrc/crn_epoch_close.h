@@ -202,8 +202,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   // The opaque values are 32-bit LDS offsets, not generic pointers: through a generic pointer every
   // access below became a FLAT instruction followed by s_waitcnt vmcnt(0), which also drained the
   // next frame's prefetch at every epoch close.
-  const unsigned tab_off = c.lds_base + (unsigned)((G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * R3) * sizeof(cx));
-  const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * G::GROUP_CPLX * sizeof(cx));
+  const unsigned tab_off = c.lds_base + (unsigned)((G::GROUPS * C::NBUF * Lay<C>::GROUP_CPLX + 16 * R3) * sizeof(cx));
+  const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * Lay<C>::GROUP_CPLX * sizeof(cx));
   const lds_i32 *tab = reinterpret_cast<const lds_i32 *>(tab_off);
   const lds_f32 *thr = reinterpret_cast<const lds_f32 *>(tab_off + 416 * 4);
   const lds_f64 *w_ih = reinterpret_cast<const lds_f64 *>(tab_off + 544 * 4);  // [5][6]
@@ -228,7 +228,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     const int sh = p.aligned_shift;   // uniform
     const int G = 1 << (sh - 4), nb = p.n_bands, al = (tid >> 4) & 3, r = m_lo & (G - 1), grp_b = m_lo >> (sh - 4);
     constexpr int kStride = 72;       // floats per a-row of partials: 72 mod 32 = 8 keeps a wave's rows on distinct banks
-    lds_f32 *mine = reinterpret_cast<lds_f32 *>(c.lds_base + (unsigned)(4 * c.wave * G::ROW * sizeof(cx))) + al * kStride;
+    lds_f32 *mine = reinterpret_cast<lds_f32 *>(c.lds_base + (unsigned)(4 * c.wave * Lay<C>::ROW * sizeof(cx))) + al * kStride;
     const float thr_lane = thr[tid & 63];
 #pragma unroll
     for (int d = 0; d < 16; d++) {
@@ -249,7 +249,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       if (b < nb) {
 #pragma unroll
         for (int w4 = 0; w4 < 4; w4++) {
-          const lds_f32 *src = reinterpret_cast<const lds_f32 *>(c.lds_base + (unsigned)(4 * w4 * G::ROW * sizeof(cx)));
+          const lds_f32 *src = reinterpret_cast<const lds_f32 *>(c.lds_base + (unsigned)(4 * w4 * Lay<C>::ROW * sizeof(cx)));
           const float a0 = src[b], a1 = src[kStride + b], a2 = src[2 * kStride + b], a3 = src[3 * kStride + b];
           sum += a0;
           sum += a1;

@@ -133,6 +133,9 @@ enum : int {
   kTw2Early = 32768, // TW2LDS: the first block of pass-2 twiddles is read from LDS before the butterflies that precede its use
   kAlignedBands = 65536, // N = 4096, equal contiguous bands of 64 / 128 / 256 bins (p.aligned_shift): band sums by DPP + one barrier
   kSc16 = 131072,   // samples in HBM are the radio's wire format (two int16 per complex sample, 4 bytes): converted in pass 1
+  kX2Wide = 524288, // A/B build only (variants 25, 26), N = 4096: exchange rows of T + 2 R3 complex, exchange-2 slots padded to 18 so that a thread's
+                    // 16 values are 16-byte aligned and come back as 8 ds_read_b128 instead of 16 ds_read_b64; odd exchange-1 rows start 16
+                    // complex later (keeps the two rows of a 32-lane read group on different banks)
   kRowsRT = 262144, // A/B build only (variant 24), N = 4096: pass 3 and the accumulate skip, by wave-uniform branches on the launch's
                     // acc_mask, the 256-bin rows no band touches — kRows' pruning decided at run time.  Measured SLOWER than forming
                     // every row (80.3 vs 82.4 % on the reference plan, 77.0 vs 81.0 % on a dense one): a dozen scalar branches
@@ -148,6 +151,15 @@ struct Cfg {
                         PK = PK_;
   static constexpr bool SC16 = (OPT_ & 131072) != 0;   // kSc16
   static constexpr unsigned SB = SC16 ? 4u : 8u;       // bytes per complex sample in HBM
+};
+
+// Exchange-buffer layout of a kernel configuration: the row length (Geo's, or the wide form of kX2Wide).
+template <class C>
+struct Lay {
+  static constexpr bool WIDE = (C::OPT & kX2Wide) != 0 && C::R3 == 16;
+  static constexpr int ROW = WIDE ? Geo<C::R3>::T + 2 * C::R3 : Geo<C::R3>::ROW;
+  static constexpr int GROUP_CPLX = 16 * ROW;
+  static constexpr int X2PAD = WIDE ? 18 : 17;   // complex slots between the 16-value runs of exchange 2 (R3 = 16)
 };
 
 // Per-thread state that lives across the frames of an epoch.
@@ -222,7 +234,7 @@ CRN_DEV void ph_pass1(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook
 template <class C>
 CRN_DEV void ph_x1_write(const cx (&v)[16], cx *buf, FrameCtx<C> &c) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) buf[i * Geo<C::R3>::ROW + c.t] = v[i];
+  for (int i = 0; i < 16; i++) buf[i * Lay<C>::ROW + (Lay<C>::WIDE ? 16 * (i & 1) : 0) + c.t] = v[i];
 }
 // Sixteen ds_read_b64 from one base address + immediate offsets, and the wait for them, as one
 // asm block.  hipcc merges adjacent reads into ds_read2_b64, which moves half the bytes per LDS
@@ -285,9 +297,28 @@ CRN_DEV void lds_wait8(cx (&w)[8]) {
                : "memory");
 }
 
+// Sixteen consecutive complex values (128 bytes, 16-byte aligned) as eight ds_read_b128 + the wait, one block.
+typedef float cx2 __attribute__((ext_vector_type(4)));
+CRN_DEV void lds_read8_b128(cx (&u)[16], const cx *base) {
+  const unsigned addr = (unsigned)(size_t)base;
+  cx2 q[8];
+  asm volatile(
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+      "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+      : "v"(addr)
+      : "memory");
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u[2 * i] = cx{q[i].x, q[i].y};
+    u[2 * i + 1] = cx{q[i].z, q[i].w};
+  }
+}
+
 template <class C>
 CRN_DEV void ph_x1_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
-  const cx *row = buf + c.a * Geo<C::R3>::ROW;
+  const cx *row = buf + c.a * Lay<C>::ROW + (Lay<C>::WIDE ? 16 * (c.a & 1) : 0);
   if constexpr ((C::OPT & kLdsBlk) != 0) {
     lds_read16_b64<C::R3 * 8>(u, row + c.m_lo);
     return;
@@ -331,14 +362,23 @@ CRN_DEV void ph_pass2(cx (&u)[16], cx (&v)[16], FrameCtx<C> &c, const Hook &hook
 template <class C>
 CRN_DEV void ph_x2_write(const cx (&v)[16], cx *buf, FrameCtx<C> &c) {
   constexpr int R3 = C::R3, J = Geo<R3>::J;
-  cx *row = buf + c.a * Geo<R3>::ROW;
+  cx *row = buf + c.a * Lay<C>::ROW;
+  if constexpr (Lay<C>::WIDE) {
+#pragma unroll
+    for (int cc = 0; cc < 16; cc++) row[cc * Lay<C>::X2PAD + c.m_lo] = v[cc];
+    return;
+  }
 #pragma unroll
   for (int cc = 0; cc < 16; cc++) row[cc * R3 + c.m_lo + cc / J] = v[cc];
 }
 template <class C>
 CRN_DEV void ph_x2_read(cx (&u)[16], cx *buf, FrameCtx<C> &c) {
   constexpr int R3 = C::R3, J = Geo<R3>::J;
-  const cx *row = buf + c.a * Geo<R3>::ROW;
+  const cx *row = buf + c.a * Lay<C>::ROW;
+  if constexpr (Lay<C>::WIDE) {
+    lds_read8_b128(u, row + Lay<C>::X2PAD * c.m_lo);
+    return;
+  }
   if constexpr ((C::OPT & kLdsBlk) != 0 && R3 == 16) {
     lds_read16_b64<8>(u, row + 17 * c.m_lo);
     return;
@@ -537,7 +577,7 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
                            __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), unsigned voff = 0,
                            unsigned soff_next = 0) {
   using G = Geo<C::R3>;
-  cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * G::GROUP_CPLX : 0);
+  cx *buf = c.gbuf + (C::NBUF == 2 ? (f & 1) * Lay<C>::GROUP_CPLX : 0);
   cx v[16];
   if constexpr (SPREAD) {
     static_assert(C::ABL == 0, "ablations use the plain path");
@@ -597,7 +637,7 @@ template <class C>
 CRN_DEV void frame_pair_compute(cx (&ua)[16], cx (&ub)[16], FrameCtx<C> &c) {
   using G = Geo<C::R3>;
   static_assert(C::NBUF == 2, "the frame pair uses one exchange buffer per frame");
-  cx *bufa = c.gbuf, *bufb = c.gbuf + G::GROUP_CPLX;
+  cx *bufa = c.gbuf, *bufb = c.gbuf + Lay<C>::GROUP_CPLX;
   cx va[16], vb[16];
   ph_pass1<C>(ua, va, c);
   group_sync<C>();               // every wave is done reading both buffers (previous pair)

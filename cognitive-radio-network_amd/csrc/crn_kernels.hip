@@ -56,6 +56,9 @@ static constexpr VariantDesc kVariants[] = {
     /* 22 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the plain form (16 window registers, twiddles read where used)
     /* 23 */ {1, 1, 1, 0, 3, 0, 1},  // the default's work at 3 workgroups/CU with all twiddles in registers (fewer instructions, less LDS)
     /* 24 */ {1, 1, 1, 1, 4, 0, 1},  // the default with its pass-3 rows chosen at run time from the handle's band table (kRowsRT)
+    /* 25 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the default + exchange 2 read back as 8 ds_read_b128 (rows of 288, slots padded to 18)
+    /* 26 */ {1, 1, 1, 0, 2, 0, 1},  // windowed kernels: pass-2 twiddles in registers (no LDS twiddle reads) at 2 workgroups per CU
+    /* 27 */ {2, 1, 1, 0, 2, 0, 1},  // windowed kernels: 26 + two exchange buffers (one barrier per frame)
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
 static constexpr int kDefaultVariant = 13;
@@ -65,6 +68,19 @@ template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
 #ifdef CRN_AB_VARIANTS
+  if constexpr (R3 == 16) {
+    if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && variant >= 25 && variant <= 27) {
+      // A/B set of the Welch kernel's LDS traffic (N = 4096): 25 wide exchange rows + ds_read_b128; 26 / 27 twiddles in registers
+      constexpr int kW = kBase | kHannSym;
+      const bool al = p.aligned_shift != 0;
+      if (variant == 25 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kW | kTw2Early | kAlignedBands | kX2Wide>>(p, stream);
+      if (variant == 25) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kW | kTw2Early | kX2Wide>>(p, stream);
+      if (variant == 26 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, 0, true, true, kW | kAlignedBands>>(p, stream);
+      if (variant == 26) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, 0, true, true, kW>>(p, stream);
+      if (al) return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, 0, true, true, kW | kAlignedBands>>(p, stream);
+      return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, 0, true, true, kW>>(p, stream);
+    }
+  }
   if (win && !mag && p.L == Geo<R3>::N && variant >= 19 && variant <= 22) {
     // A/B set of the windowed kernel: 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2
     // twiddle reads, 21 early twiddle reads alone, 22 the plain windowed kernel
@@ -77,7 +93,9 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
   // window registers fewer; the A/B numbers are in DESIGN.md §5)
-  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant)) {
+  // (variants 2 and 23 are forms of the plain kernel: a windowed handle that selects them runs its default, not the table-window form)
+  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N &&
+      (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant || variant == 2 || variant == 23)) {
     if constexpr (R3 == 16) {  // the Welch scan's plan (equal contiguous bands): band sums without the spectrum image
       if (p.aligned_shift != 0)
         return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);

@@ -61,11 +61,11 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.m_lo = m_lo;
   c.L = p.L;
   c.rt_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)p.acc_mask);
-  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
+  c.gbuf = lds + grp * (NBUF * Lay<C>::GROUP_CPLX);
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.grp_epoch_stride = 1;
   c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
-  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  c.tw2_lds = lds + G::GROUPS * NBUF * Lay<C>::GROUP_CPLX;  // [16][R3], TW2LDS only
 #ifdef CRN_AB_VARIANTS
   if constexpr ((C::OPT & kTrace) != 0) {
     // workgroup start on the wall clock, behind the [epoch][3] close stamps (the caller's buffer holds 4 words per epoch)
@@ -82,22 +82,24 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.Kf = (float)K;
   c.invK = 1.0f / (float)K;
 
+  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
+  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * SB;
+  const unsigned fbytes = (unsigned)p.frame_stride * SB;
+  cx ua[16], ub[16];
+  // A plain streaming workgroup asks for its first frame before anything else: twiddles and tables (L2 hits, but queued behind the
+  // CU's streaming loads: ~4 us a round trip on a full machine) then arrive with it instead of ahead of it.  Measured from inside
+  // the kernel (tools/gpu_wg_placement.py): a workgroup's first epoch took 26 us longer than its later ones.
+  constexpr bool kEarlyLoad = !C::WIN && (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH;
+  if constexpr (kEarlyLoad) {
+    const StreamSpan sp0 = stream_span<R3>(p);
+    load_frame<R3, NT, SC>(ua, group_rsrc<R3, (int)SB>(p, sp0.g0, sp0.epw), voff, 0u, C::FULL ? G::N : c.L);
+  }
+
   // frame-invariant twiddles, kept in registers across frames and epochs
 #pragma unroll
   for (int i = 1; i < ((C::OPT & kTw1C) != 0 ? 9 : 16); i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
   if constexpr ((C::OPT & kTw1C) != 0) c.tw1[0] = reinterpret_cast<const cx *>(p.tw1)[16 * T + t];  // W_N^{16 t}
-  {
-    // band table -> LDS (2 KiB behind the exchange buffers and the tw2 table): the epoch close walks
-    // it, and from global memory every walk step was a dependent ~1 us vector load
-    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
-    tab[tid] = p.band_tab[tid];
-    tab[tid + 256] = p.band_tab[tid + 256];
-    if (tid < kBandTabWords - 512) tab[tid + 512] = p.band_tab[tid + 512];  // row entries
-  }
-  if constexpr (C::TW2LDS) {
-    if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = reinterpret_cast<const cx *>(p.tw2)[tid];
-  }
-  __syncthreads();
+  // (register-resident tables are requested ahead of the barrier too: nothing after it starts another round trip)
   if constexpr (!C::TW2LDS) {
 #pragma unroll
     for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + m_lo];
@@ -109,14 +111,26 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 #pragma unroll
     for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
   }
+  {
+    // band table -> LDS (2 KiB behind the exchange buffers and the tw2 table): the epoch close walks
+    // it, and from global memory every walk step was a dependent ~1 us vector load.  Every load of the prologue is issued before the
+    // first LDS write (unconditional loads, clamped indices): one wait for all of them instead of three round trips in a row.
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * Lay<C>::GROUP_CPLX + 16 * R3);
+    const int w0 = p.band_tab[tid], w1 = p.band_tab[tid + 256];
+    const int w2 = p.band_tab[tid < kBandTabWords - 512 ? tid + 512 : kBandTabWords - 1];  // row entries
+    [[maybe_unused]] cx tw2v = cx{0.f, 0.f};
+    if constexpr (C::TW2LDS) tw2v = reinterpret_cast<const cx *>(p.tw2)[tid < 16 * R3 ? tid : 16 * R3 - 1];
+    tab[tid] = w0;
+    tab[tid + 256] = w1;
+    if (tid < kBandTabWords - 512) tab[tid + 512] = w2;
+    if constexpr (C::TW2LDS) {
+      if (tid < 16 * R3) lds[G::GROUPS * NBUF * Lay<C>::GROUP_CPLX + tid] = tw2v;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
 
-  constexpr unsigned kNowhere = 0x80000000u;  // scalar offset past every window: dropped by the range check
-  const unsigned voff = (unsigned)(grp * (unsigned)p.epoch_stride + t) * SB;
-  const unsigned fbytes = (unsigned)p.frame_stride * SB;
-
-  cx ua[16], ub[16];
 #ifdef CRN_AB_VARIANTS
   [[maybe_unused]] cx u0[16];   // ablations that do not re-load: the first frame, kept
 #endif
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   {
     const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3, (int)SB>(p, blockIdx.x);
-    load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
+    if constexpr (!kEarlyLoad) load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);   // one epoch group per workgroup
 #ifdef CRN_AB_VARIANTS
     if constexpr (C::ABL >= 2) {
 #pragma unroll
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       const long long g0 = sp.g0;
       const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
       const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
-      load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);
+      if constexpr (!kEarlyLoad) load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);   // windowed kernels: after the tables
       int j = 0, f = 0;
 #define CRN_STREAM_STEP(CUR, NXT)                                                                   \
       {                                                                                             \
@@ -347,7 +361,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
     q.tail_groups_per_wg = 1;
     grid = (unsigned)n_groups;
   }
-  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * Lay<C>::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
   if (lds > 48 * 1024) {

@@ -41,7 +41,7 @@ for b in range(64):
     wcfg.thresh[b] = 4.0 * 64 * 4096 * 1e-6 * 0.375
 wiq, _ = signals.make_epochs(wcfg, 6, seed=78)
 wbase = None
-for v in (0, 19, 20, 21, 22):                # the windowed kernel's A/B set
+for v in (0, 19, 20, 21, 22, 25, 26, 27):    # the windowed kernel's A/B set (25-27: the LDS-traffic forms; their spectrum path too)
     s = cs.Sensor(wcfg)
     s.set_variant(v)
     got = s.run_host(wiq, 6)
@@ -51,4 +51,17 @@ for v in (0, 19, 20, 21, 22):                # the windowed kernel's A/B set
     else:
         assert np.allclose(got["features"], wbase["features"], rtol=2e-6, atol=0), v
         assert np.array_equal(got["occupancy"], wbase["occupancy"]), v
+# ... and with a per-bin spectrum asked for (the LDS form of the close instead of the aligned-band one)
+sbase = None
+wtruth_cfg = wcfg
+for v in (0, 25, 26, 27):
+    s = cs.Sensor(wcfg)
+    s.set_variant(v)
+    got = s.run_host(wiq, 6, want_spectrum=True)
+    s.close()
+    if sbase is None:
+        sbase = got
+    else:
+        assert np.allclose(got["spectrum"], sbase["spectrum"], rtol=2e-6, atol=0), v
+        assert np.allclose(got["features"], sbase["features"], rtol=2e-6, atol=0), v
 print("variants agree")
