@@ -175,7 +175,14 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--fft", type=int, default=4096, help="FFT length N (headline: 4096)")
-    ap.add_argument("--epochs", type=int, default=0, help="decision epochs per GPU per step (0 = 8.75 GiB of IQ)")
+    ap.add_argument("--epochs", type=int, default=0,
+                    help="decision epochs per step: per GPU with --scaling weak, in total with --scaling strong (0 = 8.75 GiB of IQ)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every GPU takes --epochs epochs per step, the job grows with N.  strong: --epochs is the "
+                         "whole job (the N = 1 batch), split evenly over the ranks; a share under 4 GiB alternates its launches "
+                         "between two streams so that one launch's ramp and drain overlap the next")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="alternate the launches between two streams whatever the batch size (what --scaling strong does by itself below 4 GiB per GPU)")
     ap.add_argument("--mode", choices=["energy", "ref", "welch", "scan"], default="energy",
                     help="scan = cfg4's wideband scan: the welch kernel, streams of 64 channels sharded over the ranks")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
@@ -270,10 +277,15 @@ def main():
         workload += f" [K={args.frames}]"
     N, K = cfg.fft_len, cfg.frames_per_epoch
     spe = cs.samples_per_epoch(cfg)
-    E = args.epochs if args.epochs > 0 else (28672 * 40960) // spe   # per GPU (weak scaling)
+    E_arg = args.epochs if args.epochs > 0 else (28672 * 40960) // spe
+    # weak scaling: E_arg epochs on every GPU.  strong scaling: E_arg epochs in all — the N = 1 batch — dealt evenly (the exchange
+    # carries equal blocks: a remainder of < N epochs is left out and the job size printed is what ran)
+    E = E_arg if args.scaling == "weak" else max(1, E_arg // world)
     n_samples = cs.samples_needed(cfg, E)
     lo, hi = shard(E * world, rank, world)
     assert hi - lo == E
+    # a small share per GPU: ramp + drain are > 9 % of a 1 GiB launch (profiles/r03_batch_timeline.txt); two streams overlap them
+    two_streams = args.two_streams or (args.scaling == "strong" and E * spe * 8 < (4 << 30))
 
     sensor = cs.Sensor(cfg)
     sensor.set_variant(args.variant)
@@ -288,11 +300,12 @@ def main():
 
     iq = torch.zeros(n_samples * 2, dtype=torch.float32, device=dev)
     truth = torch.empty(E, dtype=torch.int32, device=dev)
-    feats = torch.empty(E, cfg.n_bands, dtype=torch.float32, device=dev)
-    occ = torch.empty(E, cfg.n_bands, dtype=torch.uint8, device=dev)
-    dec = torch.empty(E, dtype=torch.int32, device=dev)
-    ann = torch.empty(E, 3, dtype=torch.float64, device=dev)
+    n_sets = 2 if two_streams else 1      # launches in flight at once never share an output buffer: one set per stream
+    sets = [{"feats": torch.empty(E, cfg.n_bands, dtype=torch.float32, device=dev), "occ": torch.empty(E, cfg.n_bands, dtype=torch.uint8, device=dev),
+             "dec": torch.empty(E, dtype=torch.int32, device=dev), "ann": torch.empty(E, 3, dtype=torch.float64, device=dev)} for _ in range(n_sets)]
+    feats, occ, dec, ann = (sets[0][k] for k in ("feats", "occ", "dec", "ann"))
     stream = torch.cuda.current_stream().cuda_stream
+    tstreams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if two_streams else [torch.cuda.current_stream()]
     if args.zeros:
         args.no_check, args.cpu_epochs, args.no_alt = True, 0, True
         truth.zero_()
@@ -315,8 +328,9 @@ def main():
         sensor.pack_sc16_device(iq.data_ptr(), n_samples, wire.data_ptr(), stream=stream)
         src, sample_bytes = wire, 4
         workload += " [NOT THE HEADLINE CONFIGURATION: samples held in HBM in the radio's wire format, int16 pairs = 4 B per sample, converted in the kernel's first pass; outputs bit-identical to the float path]"
-    outs = {"features": feats.data_ptr(), "ann_out": ann.data_ptr(), "decision": dec.data_ptr(),
-            "occupancy": occ.data_ptr(), "spectrum": 0}
+    out_sets = [{"features": t["feats"].data_ptr(), "ann_out": t["ann"].data_ptr(), "decision": t["dec"].data_ptr(),
+                 "occupancy": t["occ"].data_ptr(), "spectrum": 0} for t in sets]
+    outs = out_sets[0]
     noise_floor = None
     if args.mode in ("welch", "scan") and not args.zeros:
         # SURVEY.md §8(d) cfg2 as worded: thr_b = lambda x NF_est, NF_est = the median band energy — measured on this rank's own
@@ -331,20 +345,25 @@ def main():
         noise_floor = {"estimate_median_band_energy": nf, "generator_expectation": analytic, "lambda": 4.0}
     # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the
     # all-gather of step i (side stream) overlaps the sensing kernel of step i + 1
-    ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world) if multi else (None, "")
+    # (two streams: four slots, so that a stream's next launch never waits for the gather of its previous one)
+    ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world, depth=4 if two_streams else 2) if multi else (None, "")
+    torch.cuda.synchronize()   # the set-up above ran on the current stream; the timed launches may run on others
     n_done = 0
 
-    def step(sn, epochs, out_ptrs, ev=None):
+    def step(sn, epochs, ev=None):
+        """One pass of the hot path over this rank's batch: launch i goes to stream i mod (1 or 2) with that stream's output set."""
         nonlocal n_done
+        ts, out_ptrs = tstreams[n_done % len(tstreams)], out_sets[n_done % n_sets]
+        st = ts.cuda_stream
         if ex is not None:
-            out_ptrs["occupancy"] = ex.local_ptr(n_done, stream)
+            out_ptrs["occupancy"] = ex.local_ptr(n_done, st)
         if ev is not None:
-            ev[0].record()
-        sn.run_device(src.data_ptr(), epochs, N, out_ptrs, stream=stream, sc16=sample_bytes == 4)
+            ev[0].record(ts)
+        sn.run_device(src.data_ptr(), epochs, N, out_ptrs, stream=st, sc16=sample_bytes == 4)
         if ev is not None:
-            ev[1].record()
+            ev[1].record(ts)
         if ex is not None:
-            ex.exchange(n_done, stream)
+            ex.exchange(n_done, st)
         n_done += 1
 
     def barrier():
@@ -357,19 +376,23 @@ def main():
     # per-launch time settles, so the W warm-up steps are topped up to at least
     # ~50 ms of untimed work when W is small.  The timed region below is exactly K steps.
     prewarm = max(args.warmup, int(0.05 / 1.6e-3 * (28672 * 40960) / max(E * spe, 1)) + 1)
-    for _ in range(prewarm):
-        step(sensor, E, outs)
+    for _ in range(prewarm + (prewarm + n_done) % len(tstreams)):   # (the timed region starts on stream 0)
+        step(sensor, E)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    span0 = torch.cuda.Event(enable_timing=True)
+    span1 = [torch.cuda.Event(enable_timing=True) for _ in tstreams]
 
     barrier()
     t0 = time.perf_counter()
-    span[0].record()
+    span0.record(tstreams[0])
+    for ts in tstreams[1:]:
+        ts.wait_event(span0)
     for i in range(args.steps):
-        step(sensor, E, outs, None if args.span_events else ev[i])
-    if ex is not None:
-        ex.finish(stream)
-    span[1].record()
+        step(sensor, E, None if args.span_events else ev[i])
+    for ts, e1 in zip(tstreams, span1):
+        if ex is not None:
+            ex.finish(ts.cuda_stream)
+        e1.record(ts)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -379,10 +402,14 @@ def main():
 
     # Kernel duration from events on the launch stream: one pair per launch (default), so min / median /
     # max are real per-launch figures; --span-events: one pair around the K back-to-back launches.
-    if args.span_events:
-        kern_ms = [span[0].elapsed_time(span[1]) / args.steps]
+    # Two streams: launches overlap, so a launch's own event pair also spans part of its neighbour — the duration that
+    # prices the roofline is then the span from the first launch to the last event on either stream, per launch.
+    span_ms = max(span0.elapsed_time(e1) for e1 in span1)
+    per_launch_ms = None if args.span_events else [a.elapsed_time(b) for a, b in ev]
+    if args.span_events or two_streams:
+        kern_ms = [span_ms / args.steps]
     else:
-        kern_ms = [a.elapsed_time(b) for a, b in ev]
+        kern_ms = per_launch_ms
     kern_ms_mean = float(np.mean(kern_ms))
     samples_per_step = E * spe * world
     value = samples_per_step * args.steps / dt / 1e6  # Msamples/s, whole job
@@ -391,6 +418,7 @@ def main():
 
     # ---- sanity on the timed outputs ----------------------------------------------------------------
     last = n_done - 1
+    feats, occ, dec, ann = (sets[last % n_sets][k] for k in ("feats", "occ", "dec", "ann"))   # what the last timed launch wrote
     occ_host = ex.local_host(last) if ex is not None else occ.cpu().numpy()
     picked = truth.cpu().numpy()
     if args.no_check:
@@ -547,62 +575,6 @@ def main():
         alt["unpruned"] = dict(leg(s2, E), kernel=s2.kernel_info()["name"],
                                note="what any band table outside the reference plan's rows, or a spectrum request, runs")
         s2.close()
-        # The same traffic as a radio delivers it: 16-bit integer samples (the reference's USRPs send sc16 over the wire, UHD hands
-        # the engine complex floats: src/extensible_cognitive_radio.cpp:1071-1072, 1263-1265).  Same kernel, same bytes; fewer
-        # mantissa bits toggle, so the package draws less and holds a higher clock under its power cap.
-        iq_q = torch.zeros_like(iq)
-        sc = cs.SynthCfg()
-        sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 0xC0FFEE, 1e-6, 0.02, 8
-        sc.pu_model, sc.signal_kind, sc.n_streams, sc.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, 16
-        sensor.synth_fill_device_ex(iq_q.data_ptr(), E, spe, sc, stream=stream)
-        keep = [torch.empty_like(t) for t in (feats, ann, dec, occ)]   # its results go elsewhere: the checks below read the headline's
-        outs_q = {"features": keep[0].data_ptr(), "ann_out": keep[1].data_ptr(), "decision": keep[2].data_ptr(),
-                  "occupancy": keep[3].data_ptr(), "spectrum": 0}
-        # interleaved with the headline's own input, in blocks of 10 launches (~15 ms: long enough for the clock to settle, short
-        # enough that both inputs see the same package temperature), 6 blocks each, the first 3 launches of a block not counted
-        ms = {"fp32": [], "adc16": []}
-        for _ in range(6):
-            for name, src in (("fp32", iq), ("adc16", iq_q)):
-                pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-                for a, b in pairs:
-                    a.record()
-                    sensor.run_device(src.data_ptr(), E, N, outs_q, stream=stream)
-                    b.record()
-                torch.cuda.synchronize()
-                ms[name] += [a.elapsed_time(b) for a, b in pairs[3:]]
-
-        def frac_of(v):
-            return E * spe * 8 / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS
-        alt["adc16_input"] = {"epochs": E, "bytes_per_step": E * spe * 8, "kernel_ms_mean": float(np.mean(ms["adc16"])),
-                              "kernel_ms_median": float(np.median(ms["adc16"])), "GB/s": frac_of(ms["adc16"]) * HBM_PEAK_GBS,
-                              "frac": frac_of(ms["adc16"]), "Msamples/s": E * spe / (float(np.mean(ms["adc16"])) * 1e-3) / 1e6,
-                              "frac_fp32_input_interleaved": frac_of(ms["fp32"]), "kernel": info["name"][:40] + "...",
-                              "note": "same batch with every sample rounded to 16 bits on the grid 2^-15 (crn_synth_cfg.adc_bits = 16: the "
-                                      "information a radio's samples carry; a converter constant that is not a power of two, like UHD's "
-                                      "1/32767, fills the mantissas again and keeps about half of the effect: --uhd-scale); measured in blocks "
-                                      "of 10 launches interleaved with the headline's full-precision fp32 input "
-                                      "(frac_fp32_input_interleaved), which is the worst case for power"}
-        # ... and held in HBM in that wire format (int16 pairs, 4 B per complex sample: crn_sense_run_device_sc16): half the bytes
-        # per sample, converted in the kernel's first pass, outputs bit-identical to the float path on the same samples
-        wire = torch.empty(n_samples * 2, dtype=torch.int16, device=dev)
-        sensor.pack_sc16_device(iq_q.data_ptr(), n_samples, wire.data_ptr(), stream=stream)
-        for _ in range(20):
-            sensor.run_device(wire.data_ptr(), E, N, outs_q, stream=stream, sc16=True)
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-        for a, b in pairs:
-            a.record()
-            sensor.run_device(wire.data_ptr(), E, N, outs_q, stream=stream, sc16=True)
-            b.record()
-        torch.cuda.synchronize()
-        wms = [a.elapsed_time(b) for a, b in pairs]
-        wgbs = E * spe * 4 / (float(np.mean(wms)) * 1e-3) / 1e9
-        alt["wire_format_sc16"] = {"epochs": E, "bytes_per_step": E * spe * 4, "kernel_ms_mean": float(np.mean(wms)),
-                                   "kernel_ms_median": float(np.median(wms)), "GB/s": wgbs, "frac": wgbs / HBM_PEAK_GBS,
-                                   "Msamples/s": E * spe / (float(np.mean(wms)) * 1e-3) / 1e6,
-                                   "note": "NOT the headline configuration (which reads complex floats, 8 B per sample): the same samples as "
-                                           "adc16_input kept in HBM as int16 pairs, 4 B per sample; the kernel is then bound by the vector "
-                                           "unit at the power cap, not by HBM, so Msamples/s is the figure to read, not frac"}
-        del iq_q, keep, wire
 
     # ---- CPU baseline ---------------------------------------------------------------------------------
     cpu = None
@@ -665,24 +637,51 @@ def main():
                                         "reference's own topology (one CE pthread, src/extensible_cognitive_radio.cpp:1761-1808)",
                               "passes": one_rates}}
 
+    # ---- N > 1: what every rank measured and what RCCL itself says the communicator is ------------------
+    rccl, per_rank = None, None
+    if ex is not None:
+        mine = {"rank": rank, "device": local_rank, "kernel_ms_mean": kern_ms_mean, "frac": achieved / HBM_PEAK_GBS, "comm": ex.info()}
+        everyone = [mine]
+        if world > 1:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+        comms = [r["comm"] for r in everyone]
+        rccl = {"nranks": comms[0]["nranks"], "nranks_seen_by_every_rank": sorted({c["nranks"] for c in comms}),
+                "user_ranks": [c["rank"] for c in comms], "rank0_device": comms[0]["rccl_device"],
+                "devices": [c["rccl_device"] for c in comms], "version": comms[0]["rccl_version"], "library": comms[0]["library"],
+                "gathers_per_rank": sorted({c["gathers"] for c in comms}), "bytes_per_rank_per_gather": comms[0]["bytes_per_rank"],
+                "source": "crn_comm_info on every rank: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion of the "
+                          "communicator the gathers ran on (version 0 = a stand-in library behind $CRN_RCCL_LIB)"}
+        if rccl["nranks_seen_by_every_rank"] != [world] or rccl["user_ranks"] != list(range(world)):
+            raise SystemExit(f"bench: the communicator is not the {world} ranks of this job: {rccl}")
+        slow = max(everyone, key=lambda r: r["kernel_ms_mean"])
+        fast = min(everyone, key=lambda r: r["kernel_ms_mean"])
+        per_rank = {"kernel_ms_mean": [r["kernel_ms_mean"] for r in everyone], "kernel_ms_mean_min": fast["kernel_ms_mean"],
+                    "kernel_ms_mean_max": slow["kernel_ms_mean"], "slowest_rank": slow["rank"], "frac_slowest_rank": slow["frac"],
+                    "frac_fastest_rank": fast["frac"]}
+
     if rank == 0:
         if os.environ.get("CRN_BENCH_DUMP"):
             print("kernel_ms per step:", " ".join(f"{x:.3f}" for x in kern_ms), file=sys.stderr)
         line = {
             "metric": f"Msamples/s IQ through FFT+energy-detect, {label}; % HBM roofline",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
-                       "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
+                       "epochs_per_step_all_gpus": E * world, "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
                        "parallelism": f"stream-sharded x{world}" + (", " + ex_kind if multi else ""),
+                       "streams_per_gpu": len(tstreams),
+                       **({"rccl": rccl} if rccl else {}),
                        **({"noise_floor": noise_floor} if noise_floor else {}),
                        "alt": alt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_mean": kern_ms_mean, "kernel_ms_min": float(np.min(kern_ms)),
                          "kernel_ms_median": float(np.median(kern_ms)), "kernel_ms_max": float(np.max(kern_ms)),
-                         "events": "span" if args.span_events else "per-launch"},
+                         "events": ("span over two streams (launches overlap: first launch to last event) / steps" if two_streams
+                                    else "span" if args.span_events else "per-launch"),
+                         **({"per_rank": per_rank} if per_rank else {})},
             "cpu_baseline": cpu,
         }
         if roofline_valu is not None:

@@ -120,6 +120,7 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   // replaces memset of the three buffers + fft_create_plan (.cpp:36-45)
   if (crn_sense_create(&cfg, &sensor) != CRN_OK) die_crn();
   if (crn_sense_reserve_host(sensor, 1, 0) != CRN_OK) die_crn();  // scratch + pinned staging + kernel load
+  if (mode == MODE_SCAN && crn_sense_reserve_noise_floor(sensor) != CRN_OK) die_crn();  // the calibration's upload buffers
   if (stats_on && crn_sense_set_timing(sensor, 1) != CRN_OK) die_crn();
   frame_len = cfg.fft_len;
   pad.assign((size_t)cfg.fft_len, std::complex<float>(0.f, 0.f));
@@ -127,6 +128,9 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
     // one stream; sized for full-length packets, the actual UHD packet length is
     // known only when the rx worker starts (src/extensible_cognitive_radio.cpp:1263-1265)
     if (crn_ingest_create(sensor, 1, cfg.fft_len, epochs_per_batch, &ring) != CRN_OK) die_crn();
+    // scan: the first -c epochs that come back feed the noise-floor estimate; the ring's launcher thread reduces them and sets
+    // the thresholds (this only posts the request: nothing of it ever runs on the CE thread)
+    if (mode == MODE_SCAN && crn_ingest_calibrate(ring, calib_epochs, lambda) != CRN_OK) die_crn();
   } else {
     // the longest run an epoch can need at any packet length: K packets of N (disjoint), span + one packet (overlapped)
     const size_t span = (size_t)(cfg.frames_per_epoch - 1) * cfg.hop + cfg.fft_len;
@@ -168,7 +172,7 @@ void CE_Predictive_Node_GPU::flush() {
   crn_epoch_result r;
   int32_t n = 0;
   int rc;
-  while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_epoch(r.features, r.ann_out, r.decision, r.occupancy);
+  while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_ring_epoch(r);
   if (rc != CRN_OK) die_crn();
 }
 
@@ -192,18 +196,35 @@ int CE_Predictive_Node_GPU::channel_decision(const unsigned char *occ) const {
   return 0;
 }
 
-// One epoch's results, from either path: scan-mode calibration first, then the reference's report + action block.
+// One epoch's results from the ring (enqueue-only path).  Scan mode, start-up: epochs launched before the measured thresholds were
+// in place come back marked CRN_EPOCH_CALIBRATION — they fed the estimate (crn_ingest_calibrate, on the ring's launcher thread) or
+// were decided against the thresholds of before: counted, never acted on.  The first unmarked epoch carries the estimate.
+void CE_Predictive_Node_GPU::close_ring_epoch(const crn_epoch_result &r) {
+  if (r.flags & CRN_EPOCH_CALIBRATION) {
+    epochs_calibrating++;
+    return;
+  }
+  if (calib_have < calib_epochs) {   // scan mode: the calibration has landed
+    calib_have = calib_epochs;
+    noise_floor = r.noise_floor;
+    for (int b = 0; b < cfg.n_bands; b++) cfg.thresh[b] = lambda * noise_floor;   // (this copy is for the report; the device has its own)
+    if (verbose) printf("CE_Predictive_Node_GPU: noise floor %.4e per band over %d epochs, threshold %.4e\n", noise_floor, calib_epochs, cfg.thresh[0]);
+  }
+  report(r.features, r.ann_out, mode == MODE_REF ? r.decision : channel_decision(r.occupancy));
+}
+
+// One epoch's results in the synchronous form (-a 0: execute() itself launches and waits, for offline use): scan-mode calibration
+// first, then the reference's report + action block.
 void CE_Predictive_Node_GPU::close_epoch(const float *feat, const double *out3, int kernel_decision, const unsigned char *occupancy) {
   if (calib_have < calib_epochs) {
     // scan mode, start-up: the thresholds are lambda x the measured noise floor (NF_est = the median band
-    // energy), so the first epochs only feed the estimate.  The last of them pays for one blocking upload + reduction + update.
+    // energy), so the first epochs only feed the estimate.  The last of them pays for one upload + reduction + update (no allocation:
+    // crn_sense_reserve_noise_floor ran in the constructor).
     memcpy(&calib_feat[(size_t)calib_have * cfg.n_bands], feat, sizeof(float) * (size_t)cfg.n_bands);
     epochs_calibrating++;
     if (++calib_have == calib_epochs) {
-      if (crn_noise_floor_host(sensor, calib_feat.data(), calib_epochs, &noise_floor) != CRN_OK) die_crn();
+      if (crn_sense_calibrate_thresholds(sensor, calib_feat.data(), calib_epochs, lambda, &noise_floor, NULL) != CRN_OK) die_crn();
       for (int b = 0; b < cfg.n_bands; b++) cfg.thresh[b] = lambda * noise_floor;
-      if (crn_sense_set_thresholds(sensor, cfg.thresh, cfg.n_bands, NULL) != CRN_OK) die_crn();
-      if (crn_sense_synchronize(sensor, NULL) != CRN_OK) die_crn();   // the ring launches on a stream of its own
       if (verbose) printf("CE_Predictive_Node_GPU: noise floor %.4e per band over %d epochs, threshold %.4e\n", noise_floor, calib_epochs, cfg.thresh[0]);
     }
     return;
@@ -277,7 +298,7 @@ void CE_Predictive_Node_GPU::execute() {
     crn_epoch_result r;
     int32_t n = 0;
     int rc;
-    while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_epoch(r.features, r.ann_out, r.decision, r.occupancy);
+    while ((rc = crn_ingest_poll(ring, &r, 1, &n)) == CRN_OK && n == 1) close_ring_epoch(r);
     if (rc != CRN_OK) die_crn();
   }
 

@@ -70,8 +70,8 @@ private:
   int epochs_per_batch; // -b
   float lambda;         // -t
   int calib_epochs;     // -c (scan mode)
-  int calib_have;       // epochs gathered so far; == calib_epochs once the thresholds are set
-  std::vector<float> calib_feat;          // [calib_epochs][n_bands], allocated in the constructor
+  int calib_have;       // -a 0: epochs gathered so far; both forms: == calib_epochs once the thresholds are set
+  std::vector<float> calib_feat;          // -a 0: [calib_epochs][n_bands], allocated in the constructor (the ring keeps its own)
   unsigned char ch_bands[4][CRN_MAX_BANDS];  // scan: ch_bands[k][b] != 0 when band b overlaps channel k's bins (k = 1..3)
 
   // -a 0 only: the packets of the running epoch end to end; frames are zero-padded (disjoint) or cut (Welch) by the kernel.
@@ -82,7 +82,8 @@ private:
 
   int packets_in_epoch(int L) const;       // K, or for overlapped frames ceil(((K - 1) hop + N) / L)
   int channel_decision(const unsigned char *occupancy) const;   // threshold modes: first occupied of CH1, CH2, CH3 (cascade order)
-  void close_epoch(const float *feat, const double *out3, int kernel_decision, const unsigned char *occupancy);
+  void close_epoch(const float *feat, const double *out3, int kernel_decision, const unsigned char *occupancy);   // -a 0
+  void close_ring_epoch(const crn_epoch_result &r);                                                               // enqueue-only path
 
 public:
   // results of the last closed epoch (the reference only prints them: .cpp:202-261)

@@ -19,7 +19,9 @@
  *   - a "frame" is one FFT input (N samples, of which the first L <= N come from the
  *     caller and the rest are zero: CE_Predictive_Node.cpp:37,149);
  *     an "epoch" is K consecutive frames that yield one decision (fft_averaging, .hpp:32).
- *   - thread-compatible: one handle per host thread; not internally locked.
+ *   - thread-compatible: one handle per host thread.  The one concurrency a handle is built for: an ingest ring's launcher thread
+ *     launching through it while the thread that owns it changes thresholds, weights or the band plan (crn_sense_set_thresholds /
+ *     _set_ann / _set_bands) — launches and those updates are serialised inside the handle, each launch sees one plan, whole.
  *   - every entry point that touches the GPU makes cfg.device current on the calling thread first
  *     (a new thread starts on device 0), so handles of several devices can be driven from any thread.
  */
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CRN_ABI_VERSION 2
+#define CRN_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define CRN_API __attribute__((visibility("default")))
@@ -179,6 +181,7 @@ CRN_API int crn_sense_create(const crn_cfg *cfg, crn_handle **out);
 
 /* The reference never destroys its plan (empty destructor, CE_Predictive_Node.cpp:49; no
  * `delete CE` in the ECR); a GPU-backed engine needs an explicit release. */
+/* CRN_ERR_STATE while an ingest ring is attached (its launcher thread launches through the handle): crn_ingest_destroy first. */
 CRN_API int crn_sense_destroy(crn_handle *h);
 
 /* -- the hot path --------------------------------------------------------------------------
@@ -250,7 +253,12 @@ typedef struct crn_epoch_result {
   double ann_out[3];                 /* DECIDE_ANN only                                     */
   float features[CRN_MAX_BANDS];
   uint8_t occupancy[CRN_MAX_BANDS];
+  int32_t flags;                     /* CRN_EPOCH_* bits                                    */
+  float noise_floor;                 /* the estimate the epoch's thresholds came from (crn_ingest_calibrate); 0 without one */
 } crn_epoch_result;
+/* The epoch was launched while a calibration was collecting, or before the thresholds it produced were in place: its features are
+ * measurements, its decision / occupancy were taken against the thresholds of before — not to be acted on. */
+#define CRN_EPOCH_CALIBRATION 1
 
 /* samples_per_packet: L of every pushed packet (1..fft_len) — also the largest
  * L crn_ingest_set_packet_len may select later (buffers are sized for it here, once).
@@ -268,6 +276,16 @@ CRN_API int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_
 CRN_API int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
                                    crn_ingest **out);
 CRN_API int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet);
+/* Threshold plans whose thresholds are lambda x a measured noise floor (the scan engine's start-up): the next
+ * n_epochs epochs that come back only feed the estimate — crn_noise_floor_device's median of medians over their features — and with
+ * the last of them the ring's launcher thread uploads them, reduces them and puts lambda x the estimate in as every band's
+ * threshold, ordered on the ring's stream.  Every epoch launched before that update comes out of crn_ingest_poll marked
+ * CRN_EPOCH_CALIBRATION; the first unmarked one carries the estimate in `noise_floor`.  The call itself only posts the request
+ * (no HIP call, no allocation: the buffers were made by crn_ingest_create), so an engine may issue it from execute();
+ * CRN_ERR_STATE while an earlier request is still collecting, or on a handle that does not decide by thresholds. */
+CRN_API int crn_ingest_calibrate(crn_ingest *g, int32_t n_epochs, float lambda);
+/* The estimate in force (0 before the first calibration has finished) and whether one is collecting now.  Never blocks. */
+CRN_API int crn_ingest_noise_floor(crn_ingest *g, float *nf_out, int32_t *calibrating);
 /* Packets of a different length (<= the creation length) from now on: the rx worker learns the UHD
  * packet size only when it starts (src/extensible_cognitive_radio.cpp:1263-1265), after the engine
  * was constructed.  CRN_ERR_STATE while epochs are staged. */
@@ -337,6 +355,22 @@ CRN_API int crn_comm_unique_id(uint8_t id[CRN_COMM_ID_BYTES]);
  * non-collective probe: bench.py / sharding.py do exactly that). */
 CRN_API int crn_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[CRN_COMM_ID_BYTES],
                             int64_t bytes_per_rank, int32_t depth, crn_comm **out);
+/* What the communicator is, asked of RCCL itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion on the
+ * communicator crn_comm_create built — not an echo of its arguments), so that a caller can state, and a reader of its output can
+ * check, that the collective really spans `nranks` ranks: bench.py puts every rank's answer into its N > 1 JSON line.  Fields RCCL
+ * cannot answer (a library without the query) read -1.  Not collective; never blocks. */
+typedef struct crn_comm_info_t {
+  int32_t nranks;         /* ncclCommCount */
+  int32_t rank;           /* ncclCommUserRank */
+  int32_t rccl_device;    /* ncclCommCuDevice: the HIP device RCCL bound this rank to */
+  int32_t rccl_version;   /* ncclGetVersion (e.g. 22203) */
+  int32_t device;         /* the device crn_comm_create was given */
+  int32_t depth;
+  int64_t bytes_per_rank;
+  int64_t gathers;        /* all-gathers queued through crn_comm_allgather so far */
+  char library[128];      /* the name the RCCL library was loaded under (librccl.so.1, or $CRN_RCCL_LIB) */
+} crn_comm_info_t;
+CRN_API int crn_comm_info(crn_comm *c, crn_comm_info_t *out);
 /* Device address of the block step `step` writes (slot step % depth).  If that slot's previous gather
  * is still in flight, `stream` is made to wait for it (on the device; the host does not block). */
 CRN_API int crn_comm_local(crn_comm *c, int64_t step, void *stream, uint8_t **d_local);
@@ -482,11 +516,21 @@ CRN_API int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, flo
  * fewer than half of the bands occupied the estimate does not see the signals.  Enqueues on `stream` and waits for the result. */
 CRN_API int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream);
 /* Replace the per-band thresholds of a handle (cfg.thresh; CRN_DECIDE_THRESHOLD): ordered on `stream` — launches enqueued on it
- * after the call see the new values, launches before it the old ones.  `thresh` is read before the call returns. */
+ * after the call see the new values, launches before it the old ones.  `thresh` is read before the call returns (it is staged in
+ * pinned memory of the handle's own, one slot per update: the asynchronous copy never reads memory a later call rewrites). */
 CRN_API int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream);
 
+/* Allocate, now, what crn_noise_floor_host and crn_sense_calibrate_thresholds need (pinned + device upload buffers for 4096 epochs
+ * of CRN_MAX_BANDS features, the reduction scratch): after it neither allocates.  An engine calls it from its constructor. */
+CRN_API int crn_sense_reserve_noise_floor(crn_handle *h);
+/* Calibration in one call, for callers that hold the features on the host (the engine's synchronous form; the ingest ring's launcher
+ * thread): upload features [n_epochs][n_bands] (n_epochs <= 4096), crn_noise_floor_device, then every band's threshold = lambda x
+ * the estimate, set on `stream` like crn_sense_set_thresholds.  Blocks for the reduction; allocates nothing (CRN_ERR_STATE unless
+ * crn_sense_reserve_noise_floor ran). */
+CRN_API int crn_sense_calibrate_thresholds(crn_handle *h, const float *features, int64_t n_epochs, float lambda, float *nf_out, void *stream);
 /* The same estimate from a features matrix in host memory (an engine that keeps no device buffers of its own): uploaded, then
- * crn_noise_floor_device.  Blocking; not for the packet path. */
+ * crn_noise_floor_device.  Blocking; not for the packet path.  Allocates its upload buffers on the first call unless
+ * crn_sense_reserve_noise_floor did. */
 CRN_API int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs, float *nf_out);
 /* Replace the network of a DECIDE_ANN handle (cfg.ann_w_ih / ann_w_ho / ann_threshold; the reference has its weights as
  * literals, CE_Predictive_Node.cpp:78-120): ordered on `stream` like crn_sense_set_thresholds.  The threshold rides in the launch
@@ -495,8 +539,10 @@ CRN_API int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const doub
 /* Replace the band plan of a live handle (cfg.segs / n_segs / n_bands; the reference's is the five loops of
  * CE_Predictive_Node.cpp:173-191).  thresh: n_bands new thresholds, or NULL to keep the current ones (then n_bands must not
  * change).  Same validation as crn_sense_create.  Every table derived from the plan is rebuilt into a fresh allocation and the
- * call waits for launches in flight on the device before it frees the old one: not for the packet path.  Ingest rings size their
- * result buffers for the n_bands they were created with: create them after a call that changes n_bands. */
+ * call waits for launches in flight on the device before it frees the old one: not for the packet path.  Safe against an attached
+ * ingest ring's launcher thread: the swap and the release of the old tables happen under the handle's lock, which every launch
+ * holds from its first read of the plan until its kernel is enqueued.  Ingest rings size their result buffers for the n_bands they
+ * were created with: a call that changes n_bands is refused (CRN_ERR_STATE) while one is attached. */
 CRN_API int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs, int32_t n_bands, const float *thresh);
 
 /* Wait until everything queued on `stream` (NULL = the default stream) of the handle's device has completed: for callers that are

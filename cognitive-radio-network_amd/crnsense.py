@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense_ab.so" if os.environ.get("CRN_SENSE_AB") == "1" else "libcrnsense.so")
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
-CRN_ABI_VERSION = 2
+CRN_ABI_VERSION = 3
 CRN_ERR_ARG = -1
 CRN_ERR_BUSY = -5
 CRN_MAX_BANDS = 80
@@ -34,11 +34,12 @@ EXPORTS = [
     "crn_sense_kernel_info", "crn_sense_set_variant",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped", "crn_ingest_packets_per_epoch",
-    "crn_noise_floor_device", "crn_sense_set_thresholds",
+    "crn_noise_floor_device", "crn_sense_set_thresholds", "crn_sense_reserve_noise_floor", "crn_sense_calibrate_thresholds",
+    "crn_ingest_calibrate", "crn_ingest_noise_floor",
     "crn_sense_reserve_host", "crn_sense_set_timing", "crn_sense_get_stats", "crn_ingest_get_stats",
     "crn_monitor_rows_device",
     "crn_comm_unique_id", "crn_comm_create", "crn_comm_local", "crn_comm_allgather", "crn_comm_gathered",
-    "crn_comm_finish", "crn_comm_destroy", "crn_comm_local_addr", "crn_comm_wait",
+    "crn_comm_finish", "crn_comm_destroy", "crn_comm_local_addr", "crn_comm_wait", "crn_comm_info",
     "crn_last_error", "crn_abi_version", "crn_build_info",
 ]
 
@@ -70,7 +71,10 @@ class Out(C.Structure):
 class EpochResult(C.Structure):
     _fields_ = [("stream", C.c_int32), ("decision", C.c_int32), ("epoch_seq", C.c_int64),
                 ("ann_out", C.c_double * 3), ("features", C.c_float * CRN_MAX_BANDS),
-                ("occupancy", C.c_uint8 * CRN_MAX_BANDS)]
+                ("occupancy", C.c_uint8 * CRN_MAX_BANDS), ("flags", C.c_int32), ("noise_floor", C.c_float)]
+
+
+EPOCH_CALIBRATION = 1
 
 
 MONITOR_GNURADIO, MONITOR_PSD = 0, 1
@@ -87,6 +91,12 @@ class IngestStats(C.Structure):
     _fields_ = [("packets", C.c_int64), ("dropped", C.c_int64), ("batches", C.c_int64), ("batches_failed", C.c_int64),
                 ("epochs_launched", C.c_int64), ("epochs_ready", C.c_int64), ("epochs_polled", C.c_int64),
                 ("latency_us_sum", C.c_double), ("latency_us_max", C.c_double)]
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("rccl_device", C.c_int32), ("rccl_version", C.c_int32),
+                ("device", C.c_int32), ("depth", C.c_int32), ("bytes_per_rank", C.c_int64), ("gathers", C.c_int64),
+                ("library", C.c_char * 128)]
 
 
 class SynthCfg(C.Structure):
@@ -171,6 +181,10 @@ def lib():
         L.crn_sense_reserve_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.crn_noise_floor_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]
         L.crn_sense_set_thresholds.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p]
+        L.crn_sense_reserve_noise_floor.argtypes = [C.c_void_p]
+        L.crn_sense_calibrate_thresholds.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.POINTER(C.c_float), C.c_void_p]
+        L.crn_ingest_calibrate.argtypes = [C.c_void_p, C.c_int32, C.c_float]
+        L.crn_ingest_noise_floor.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.crn_sense_set_timing.argtypes = [C.c_void_p, C.c_int32]
         L.crn_sense_get_stats.argtypes = [C.c_void_p, C.POINTER(SenseStats)]
         L.crn_ingest_get_stats.argtypes = [C.c_void_p, C.POINTER(IngestStats)]
@@ -186,6 +200,7 @@ def lib():
         L.crn_comm_gathered.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.crn_comm_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.crn_comm_destroy.argtypes = [C.c_void_p]
+        L.crn_comm_info.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
         _lib = L
     return _lib
 
@@ -260,11 +275,14 @@ class Sensor:
     def __init__(self, cfg):
         self.cfg = cfg
         self._h = C.c_void_p()
+        self._rings = []      # Ingest objects attached to this handle: closed before it (crn_sense_destroy refuses otherwise)
         check(lib().crn_sense_create(C.byref(cfg), C.byref(self._h)), "crn_sense_create")
 
     def close(self):
         if self._h:
-            lib().crn_sense_destroy(self._h)
+            for ring in list(self._rings):
+                ring.close()
+            check(lib().crn_sense_destroy(self._h), "crn_sense_destroy")
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -311,6 +329,21 @@ class Sensor:
         if th is not None:
             for b in range(n_bands):
                 self.cfg.thresh[b] = th[b]
+
+    def reserve_noise_floor(self):
+        check(lib().crn_sense_reserve_noise_floor(self._h), "crn_sense_reserve_noise_floor")
+
+    def calibrate_thresholds(self, features, lam, stream=0):
+        """Upload a numpy [n_epochs][n_bands] float32 matrix, estimate the noise floor, set every threshold to lam x it; returns the
+        estimate and updates self.cfg."""
+        import numpy as np
+        f = np.ascontiguousarray(features, np.float32)
+        nf = C.c_float()
+        check(lib().crn_sense_calibrate_thresholds(self._h, f.ctypes.data, f.shape[0], lam, C.byref(nf), C.c_void_p(stream or None)),
+              "crn_sense_calibrate_thresholds")
+        for b in range(self.cfg.n_bands):
+            self.cfg.thresh[b] = float(np.float32(lam) * np.float32(nf.value))
+        return nf.value
 
     def noise_floor_host(self, features):
         """crn_noise_floor_host on a numpy [n_epochs][n_bands] float32 matrix."""
@@ -478,6 +511,14 @@ class Comm:
     def finish(self, stream=0):
         check(lib().crn_comm_finish(self._c, C.c_void_p(stream or None)), "crn_comm_finish")
 
+    def info(self):
+        """What RCCL says the communicator is (ncclCommCount / UserRank / CuDevice / GetVersion), as a dict."""
+        ci = CommInfo()
+        check(lib().crn_comm_info(self._c, C.byref(ci)), "crn_comm_info")
+        return {"nranks": ci.nranks, "rank": ci.rank, "rccl_device": ci.rccl_device, "rccl_version": ci.rccl_version,
+                "device": ci.device, "depth": ci.depth, "bytes_per_rank": ci.bytes_per_rank, "gathers": ci.gathers,
+                "library": ci.library.decode(errors="replace")}
+
     def close(self):
         if self._c:
             lib().crn_comm_destroy(self._c)
@@ -494,6 +535,17 @@ class Ingest:
         self._push = lib().crn_ingest_push_sc16 if sc16 else lib().crn_ingest_push
         create = lib().crn_ingest_create_sc16 if sc16 else lib().crn_ingest_create
         check(create(sensor._h, n_streams, samples_per_packet, epochs_per_batch, C.byref(self._g)), "crn_ingest_create")
+        sensor._rings.append(self)
+
+    def calibrate(self, n_epochs, lam):
+        """Post a noise-floor calibration over the next n_epochs epochs (carried out by the ring's launcher thread)."""
+        check(lib().crn_ingest_calibrate(self._g, n_epochs, lam), "crn_ingest_calibrate")
+
+    def noise_floor(self):
+        """(estimate in force, calibration collecting?)"""
+        nf, busy = C.c_float(), C.c_int32()
+        check(lib().crn_ingest_noise_floor(self._g, C.byref(nf), C.byref(busy)), "crn_ingest_noise_floor")
+        return nf.value, bool(busy.value)
 
     def push(self, stream, packet, block=True):
         """block=True: on CRN_ERR_BUSY wait for a free buffer and push again (tests, tools);
@@ -541,3 +593,5 @@ class Ingest:
         if self._g:
             lib().crn_ingest_destroy(self._g)
             self._g = C.c_void_p()
+            if self in self.sensor._rings:
+                self.sensor._rings.remove(self)

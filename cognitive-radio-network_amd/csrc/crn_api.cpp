@@ -57,6 +57,26 @@ struct crn_handle {
   size_t h_small_bytes = 0;
   void *h_results = nullptr;   // pinned staging for the per-epoch results of run_host (one D2H)
   size_t h_results_bytes = 0;
+  // Live updates against launches from other threads (an ingest ring's launcher thread calls run_device_impl while the thread that
+  // owns the handle calls crn_sense_set_bands / _set_thresholds / _set_ann): `tables_mu` covers cfg, every table pointer and the
+  // plan-derived fields above.  A launch holds it from the first read of cfg until the kernel is enqueued, an update from its
+  // first write until its copies are enqueued (set_bands: until the old slab is freed) — so a launch sees one plan, whole, and no
+  // launch can pick up a slab after the update that frees it has started.
+  std::mutex tables_mu;
+  // Pinned staging of the small asynchronous updates (thresholds, weights): hipMemcpyAsync reads its source when the stream gets
+  // there, so each update copies from a slot of its own that is not rewritten until the event behind its copies has completed.
+  struct UpdateSlot {
+    float thresh[CRN_MAX_BANDS];
+    double w_ih[CRN_ANN_IN + 1][CRN_ANN_HID + 1];
+    double w_ho[CRN_ANN_HID + 1][CRN_ANN_OUT + 1];
+  };
+  static constexpr int kUpdateSlots = 8;
+  UpdateSlot *upd = nullptr;                 // pinned [kUpdateSlots]
+  hipEvent_t upd_done[kUpdateSlots] = {};
+  bool upd_used[kUpdateSlots] = {};
+  int64_t upd_next = 0;
+  float *h_nf_features = nullptr;            // pinned upload buffer of crn_noise_floor_host (crn_sense_reserve_noise_floor)
+  float *d_nf_features = nullptr;
   // counters (crn_sense_get_stats): launches come from the caller's thread or from an ingest ring's launcher thread
   std::atomic<int64_t> n_launches{0}, n_epochs{0}, n_samples{0};
   std::mutex timing_mu;        // everything below
@@ -315,13 +335,28 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
     delete h;
     return rc;
   }
+  hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&h->upd), sizeof(crn_handle::UpdateSlot) * crn_handle::kUpdateSlots, hipHostMallocDefault);
+  for (int i = 0; i < crn_handle::kUpdateSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&h->upd_done[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    (void)crn_sense_destroy(h);
+    return crn::fail(CRN_ERR_NOMEM, std::string("crn_sense_create(update staging): ") + hipGetErrorString(e));
+  }
   *out = h;
   return CRN_OK;
 }
 
 int crn_sense_destroy(crn_handle *h) {
   if (!h) return CRN_OK;
+  // a ring's launcher thread launches through this handle and crn_ingest_destroy detaches from it: rings go first
+  if (h->n_rings.load(std::memory_order_acquire) > 0)
+    return crn::fail(CRN_ERR_STATE, "crn_sense_destroy: " + std::to_string(h->n_rings.load()) + " ingest ring(s) are still attached to this "
+                                    "handle (crn_ingest_destroy them first)");
   (void)hipSetDevice(h->cfg.device);
+  if (h->upd) (void)hipHostFree(h->upd);
+  for (int i = 0; i < crn_handle::kUpdateSlots; i++)
+    if (h->upd_done[i]) (void)hipEventDestroy(h->upd_done[i]);
+  if (h->h_nf_features) (void)hipHostFree(h->h_nf_features);
+  if (h->d_nf_features) (void)hipFree(h->d_nf_features);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->h_results) (void)hipHostFree(h->h_results);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -338,19 +373,21 @@ int crn_sense_destroy(crn_handle *h) {
 // internal (crn_ingest.cpp): a ring attaches to / detaches from its handle
 int crn_sense_ring_count(crn_handle *h, int delta) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
-  h->n_rings.fetch_add(delta, std::memory_order_relaxed);
+  h->n_rings.fetch_add(delta, std::memory_order_acq_rel);
   return CRN_OK;
 }
 
 // internal (crn_ingest.cpp): the configuration a handle was created with
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) {
   if (!h || !out) return crn::fail(CRN_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   *out = h->cfg;
   return CRN_OK;
 }
 
 int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   if (variant >= 100 && variant <= 164) {  // A/B: 100 + n = n epoch groups per workgroup (100 = automatic)
     h->groups_per_wg = variant - 100;
     return CRN_OK;
@@ -374,6 +411,7 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
 int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *threads_per_block,
                           int32_t *lds_bytes, int32_t *epochs_per_block) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   int thr = 0, lds = 0, epb = 0;
   crn::sense_geometry(h->cfg.fft_len, h->variant, &thr, &lds, &epb);
   if (threads_per_block) *threads_per_block = thr;
@@ -486,6 +524,8 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   const int64_t sample_bytes = sc16 ? 4 : 8;
   if ((reinterpret_cast<uintptr_t>(d_iq) & (uintptr_t)(sample_bytes - 1)) != 0)
     return crn::fail(CRN_ERR_ARG, sc16 ? "IQ pointer must be 4-byte aligned" : "IQ pointer must be 8-byte aligned");
+  // one plan, whole, from here until the kernel is enqueued (live updates from another thread wait; see crn_handle::tables_mu)
+  std::lock_guard<std::mutex> tables_lk(h->tables_mu);
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
@@ -600,6 +640,7 @@ int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epoc
 int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
   if (!(full_scale >= 1.0 && full_scale <= 65536.0)) return crn::fail(CRN_ERR_ARG, "full_scale must be in 1..65536");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   h->wire_full_scale = full_scale;
   return CRN_OK;
 }
@@ -607,6 +648,7 @@ int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale) {
 int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream) {
   if (!h || !d_iq || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
   if (n_samples < 0) return crn::fail(CRN_ERR_ARG, "n_samples < 0");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   HIP_TRY(hipSetDevice(h->cfg.device));
   HIP_TRY(crn::launch_pack_sc16(d_iq, n_samples, d_out, (float)h->wire_full_scale, static_cast<hipStream_t>(stream)));
   return CRN_OK;
@@ -717,34 +759,87 @@ int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t want_spect
   return crn_sense_run_host(h, zeros.data(), max_epochs, c.fft_len, 0, &o);
 }
 
-int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream) {
-  if (!h || !d_features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
-  if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+namespace {
+// The next pinned staging slot (tables_mu held): waits only if the copy that last read this slot — eight updates ago — has not finished.
+int take_update_slot(crn_handle *h, int *slot) {
+  const int i = (int)(h->upd_next++ % crn_handle::kUpdateSlots);
+  if (h->upd_used[i]) HIP_TRY(hipEventSynchronize(h->upd_done[i]));
+  h->upd_used[i] = true;
+  *slot = i;
+  return CRN_OK;
+}
+
+int noise_floor_locked(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, hipStream_t st) {
   if (!h->d_nf_scratch) HIP_TRY(hipMalloc(&h->d_nf_scratch, (crn::kNoiseFloorMaxEpochs + 1) * sizeof(float)));
   const int n = (int)std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(crn::launch_noise_floor(d_features, n, h->cfg.n_bands, h->d_nf_scratch, st));
   HIP_TRY(hipMemcpyAsync(nf_out, h->d_nf_scratch + crn::kNoiseFloorMaxEpochs, sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CRN_OK;
 }
 
+int set_thresholds_locked(crn_handle *h, const float *thresh, int32_t n_bands, hipStream_t st) {
+  int slot = 0;
+  if (int rc = take_update_slot(h, &slot)) return rc;
+  std::memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
+  float *src = h->upd[slot].thresh;
+  std::memcpy(src, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS);
+  // the two device copies the kernels read: the table and the packed band table's threshold words (layout: crn_kernels.h)
+  HIP_TRY(hipMemcpyAsync(const_cast<float *>(h->d_thresh), src, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 416, src, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(h->upd_done[slot], st));
+  return CRN_OK;
+}
+}  // namespace
+
+int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream) {
+  if (!h || !d_features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
+  if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  return noise_floor_locked(h, d_features, n_epochs, nf_out, static_cast<hipStream_t>(stream));
+}
+
+int crn_sense_reserve_noise_floor(crn_handle *h) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t bytes = (size_t)crn::kNoiseFloorMaxEpochs * CRN_MAX_BANDS * sizeof(float);   // any band plan the handle may get later
+  if (!h->d_nf_scratch) HIP_TRY(hipMalloc(&h->d_nf_scratch, (crn::kNoiseFloorMaxEpochs + 1) * sizeof(float)));
+  if (!h->h_nf_features) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_nf_features), bytes, hipHostMallocDefault));
+  if (!h->d_nf_features) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_nf_features), bytes));
+  return CRN_OK;
+}
+
 int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream) {
   if (!h || !thresh) return crn::fail(CRN_ERR_ARG, "null handle / thresholds");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   if (n_bands != h->cfg.n_bands) return crn::fail(CRN_ERR_ARG, "n_bands differs from the handle's");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  std::memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
-  // the two device copies the kernels read: the table and the packed band table's threshold words (layout: crn_kernels.h).
-  // Pageable source: the runtime stages it before the call returns, the device copy is ordered on `stream`.
+  return set_thresholds_locked(h, thresh, n_bands, static_cast<hipStream_t>(stream));
+}
+
+int crn_sense_calibrate_thresholds(crn_handle *h, const float *features, int64_t n_epochs, float lambda, float *nf_out, void *stream) {
+  if (!h || !features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
+  if (n_epochs < 1 || n_epochs > crn::kNoiseFloorMaxEpochs) return crn::fail(CRN_ERR_ARG, "n_epochs must be in 1..4096");
+  if (!(lambda > 0.f)) return crn::fail(CRN_ERR_ARG, "lambda must be positive");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
+  if (!h->h_nf_features || !h->d_nf_features || !h->d_nf_scratch)
+    return crn::fail(CRN_ERR_STATE, "crn_sense_calibrate_thresholds: call crn_sense_reserve_noise_floor first (this call allocates nothing)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemcpyAsync(const_cast<float *>(h->d_thresh), h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 416, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS, hipMemcpyHostToDevice, st));
-  return CRN_OK;
+  const size_t bytes = (size_t)n_epochs * h->cfg.n_bands * sizeof(float);
+  std::memcpy(h->h_nf_features, features, bytes);
+  HIP_TRY(hipMemcpyAsync(h->d_nf_features, h->h_nf_features, bytes, hipMemcpyHostToDevice, st));
+  if (int rc = noise_floor_locked(h, h->d_nf_features, n_epochs, nf_out, st)) return rc;
+  float thr[CRN_MAX_BANDS];
+  for (int b = 0; b < h->cfg.n_bands; b++) thr[b] = lambda * *nf_out;
+  return set_thresholds_locked(h, thr, h->cfg.n_bands, st);
 }
 
 int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[6][4], double threshold, void *stream) {
   if (!h || !w_ih || !w_ho) return crn::fail(CRN_ERR_ARG, "null handle / weights");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   if (h->cfg.decide != CRN_DECIDE_ANN) return crn::fail(CRN_ERR_STATE, "crn_sense_set_ann: the handle does not decide with the network");
   if (!(threshold > 0.0 && threshold < 1.0)) return crn::fail(CRN_ERR_ARG, "threshold must be in (0, 1)");
   for (int i = 0; i < 5; i++)
@@ -754,21 +849,30 @@ int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[
     for (int k = 0; k < 4; k++)
       if (!std::isfinite(w_ho[j][k])) return crn::fail(CRN_ERR_ARG, "non-finite weight");
   HIP_TRY(hipSetDevice(h->cfg.device));
+  int slot = 0;
+  if (int rc = take_update_slot(h, &slot)) return rc;
   std::memcpy(h->cfg.ann_w_ih, w_ih, sizeof(h->cfg.ann_w_ih));
   std::memcpy(h->cfg.ann_w_ho, w_ho, sizeof(h->cfg.ann_w_ho));
   h->cfg.ann_threshold = threshold;   // rides in the launch parameters
+  crn_handle::UpdateSlot &u = h->upd[slot];
+  std::memcpy(u.w_ih, w_ih, sizeof(u.w_ih));
+  std::memcpy(u.w_ho, w_ho, sizeof(u.w_ho));
   // the device copies the kernels read: the two tables and the packed band table's weight words (layout: crn_kernels.h)
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_wih), h->cfg.ann_w_ih, sizeof(h->cfg.ann_w_ih), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_who), h->cfg.ann_w_ho, sizeof(h->cfg.ann_w_ho), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 544, h->cfg.ann_w_ih, sizeof(h->cfg.ann_w_ih), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 604, h->cfg.ann_w_ho, sizeof(h->cfg.ann_w_ho), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_wih), u.w_ih, sizeof(u.w_ih), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->d_who), u.w_ho, sizeof(u.w_ho), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 544, u.w_ih, sizeof(u.w_ih), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(const_cast<int *>(h->d_band_tab) + 604, u.w_ho, sizeof(u.w_ho), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(h->upd_done[slot], st));
   return CRN_OK;
 }
 
 int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs, int32_t n_bands, const float *thresh) {
   if (!h || !segs) return crn::fail(CRN_ERR_ARG, "null handle / segments");
   if (n_segs < 1 || n_segs > CRN_MAX_SEGS) return crn::fail(CRN_ERR_ARG, "n_segs out of range");
+  // held across the rebuild AND the release of the old slab: a launch on another thread (an ingest ring's launcher) either was
+  // enqueued before — hipFree inside build_tables waits for it — or starts after, with the new plan, whole
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   crn_cfg next = h->cfg;
   next.n_segs = n_segs;
   next.n_bands = n_bands;
@@ -779,7 +883,7 @@ int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs,
     return crn::fail(CRN_ERR_ARG, "crn_sense_set_bands: a different number of bands needs its thresholds");
   }
   if (int rc = validate(&next)) return rc;   // same rules as crn_sense_create (DECIDE_ANN keeps its 4 bands, ref_band stays inside)
-  if (n_bands != h->cfg.n_bands && h->n_rings.load(std::memory_order_relaxed) > 0)
+  if (n_bands != h->cfg.n_bands && h->n_rings.load(std::memory_order_acquire) > 0)
     return crn::fail(CRN_ERR_STATE, "crn_sense_set_bands: an ingest ring on this handle was sized for the current number of bands "
                                     "(destroy it, change the plan, create it again)");
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -802,16 +906,14 @@ int crn_sense_synchronize(crn_handle *h, void *stream) {
 int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs, float *nf_out) {
   if (!h || !features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
   if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
+  if (int rc = crn_sense_reserve_noise_floor(h)) return rc;   // allocates on the first call only
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   HIP_TRY(hipSetDevice(h->cfg.device));
   const int64_t n = std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
   const size_t bytes = (size_t)n * h->cfg.n_bands * sizeof(float);
-  float *d = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), bytes));
-  hipError_t e = hipMemcpy(d, features, bytes, hipMemcpyHostToDevice);
-  int rc = e == hipSuccess ? crn_noise_floor_device(h, d, n, nf_out, nullptr)
-                           : crn::fail(CRN_ERR_DEVICE, std::string("hipMemcpy(features): ") + hipGetErrorString(e));
-  (void)hipFree(d);
-  return rc;
+  std::memcpy(h->h_nf_features, features, bytes);
+  HIP_TRY(hipMemcpyAsync(h->d_nf_features, h->h_nf_features, bytes, hipMemcpyHostToDevice, nullptr));
+  return noise_floor_locked(h, h->d_nf_features, n, nf_out, nullptr);
 }
 
 int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,
@@ -820,6 +922,7 @@ int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_ro
   if (n_rows < 0) return crn::fail(CRN_ERR_ARG, "n_rows < 0");
   if (kind != CRN_MONITOR_GNURADIO && kind != CRN_MONITOR_PSD) return crn::fail(CRN_ERR_ARG, "unknown monitor kind");
   if (!(alpha > 0.f && alpha <= 1.f)) return crn::fail(CRN_ERR_ARG, "alpha must be in (0, 1]");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   HIP_TRY(hipSetDevice(h->cfg.device));
   const double N = (double)h->cfg.fft_len;
   crn::MonitorParams p{};
@@ -841,6 +944,7 @@ int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, i
                            int64_t frame_stride, float *d_out, void *stream) {
   if (!h || !d_in || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
   if (n_frames < 0) return crn::fail(CRN_ERR_ARG, "negative frame count");
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   if (samples_per_frame < 1 || samples_per_frame > h->cfg.fft_len)
     return crn::fail(CRN_ERR_ARG, "samples_per_frame must be in 1..fft_len");
   if (frame_stride <= 0) frame_stride = samples_per_frame;
@@ -888,6 +992,7 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
     if (markov && !d_truth) return crn::fail(CRN_ERR_ARG, "the Markov traffic models need d_truth");
     if (n_epochs % sc->n_streams != 0) return crn::fail(CRN_ERR_ARG, "n_streams must divide n_epochs");
   }
+  std::lock_guard<std::mutex> lk(h->tables_mu);
   const crn_cfg &c = h->cfg;
   HIP_TRY(hipSetDevice(c.device));
   crn::SynthParams p{};

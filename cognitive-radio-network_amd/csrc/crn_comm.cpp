@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -39,6 +40,12 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  // what crn_comm_info reports (a library without them still gathers: the fields then read -1)
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string path;   // the name dlopen took
   std::string error;
 };
 
@@ -51,7 +58,10 @@ Rccl &rccl() {
     for (const char *n : names) {
       if (!n || !*n) continue;
       r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (r.lib) break;
+      if (r.lib) {
+        r.path = n;
+        break;
+      }
       r.error = dlerror();
     }
     if (!r.lib) return;
@@ -60,6 +70,10 @@ Rccl &rccl() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
+    r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.lib, "ncclCommCuDevice"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.lib, "ncclGetVersion"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
       r.error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
       dlclose(r.lib);
@@ -93,6 +107,7 @@ struct crn_comm {
   std::vector<hipEvent_t> ready; // launch stream: the slot's block has been written
   std::vector<hipEvent_t> done;  // side stream: the slot's gather has finished
   std::vector<char> pending;
+  int64_t n_gathers = 0;         // all-gathers queued so far (crn_comm_info)
 };
 
 extern "C" {
@@ -148,6 +163,24 @@ int crn_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t i
   return CRN_OK;
 }
 
+int crn_comm_info(crn_comm *c, crn_comm_info_t *out) {
+  if (!c || !out) return crn::fail(CRN_ERR_ARG, "crn_comm_info: null argument");
+  std::memset(out, 0, sizeof(*out));
+  out->nranks = out->rank = out->rccl_device = out->rccl_version = -1;
+  out->device = c->device;
+  out->depth = c->depth;
+  out->bytes_per_rank = c->bytes;
+  out->gathers = c->n_gathers;
+  Rccl &r = rccl();
+  // asked of the communicator RCCL built, not echoed from crn_comm_create's arguments: what the collective itself believes
+  if (r.CommCount) { int v = -1; NCCL_TRY(r.CommCount(c->comm, &v)); out->nranks = v; }
+  if (r.CommUserRank) { int v = -1; NCCL_TRY(r.CommUserRank(c->comm, &v)); out->rank = v; }
+  if (r.CommCuDevice) { int v = -1; NCCL_TRY(r.CommCuDevice(c->comm, &v)); out->rccl_device = v; }
+  if (r.GetVersion) { int v = -1; NCCL_TRY(r.GetVersion(&v)); out->rccl_version = v; }
+  std::snprintf(out->library, sizeof(out->library), "%s", r.path.c_str());
+  return CRN_OK;
+}
+
 int crn_comm_local(crn_comm *c, int64_t step, void *stream, uint8_t **d_local) {
   if (!c || !d_local || step < 0) return crn::fail(CRN_ERR_ARG, "crn_comm_local: bad argument");
   const int s = (int)(step % c->depth);
@@ -185,6 +218,7 @@ int crn_comm_allgather(crn_comm *c, int64_t step, void *stream) {
                             (size_t)c->bytes, ncclUint8, c->comm, c->side));
   HIP_TRY(hipEventRecord(c->done[s], c->side));
   c->pending[s] = 1;
+  c->n_gathers++;
   return CRN_OK;
 }
 

@@ -63,6 +63,7 @@ struct Batch {
   int complete = 0;             // of which hold all K packets
   int launched = 0;             // slots of the launch handed to the launcher thread
   int L = 0, P = 0;             // packet length and packets per epoch of that launch
+  bool calibrating = false;     // launched while a calibration was collecting or before its thresholds were in place (launcher thread)
   std::chrono::steady_clock::time_point t_handoff;   // when the pushing thread handed it over (written before state = kQueued)
   std::atomic<int> state{kFree};
 };
@@ -101,9 +102,17 @@ struct crn_ingest {
   std::atomic<bool> work_waiting{false};   // work is not empty (read by the launcher without the lock while it polls an event)
   int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
   double lat_us_sum = 0.0, lat_us_max = 0.0;
+  // ---- noise-floor calibration (crn_ingest_calibrate): requested by the caller's thread, carried out by the launcher ----
+  std::atomic<int> calib_state{0};         // 0 none / done, 1 collecting (set under mu by the caller, cleared by the launcher)
+  int calib_target = 0, calib_have = 0;    // epochs wanted / collected (launcher thread once calib_state == 1)
+  float calib_lambda = 0.f;
+  std::vector<float> calib_feat;           // [kCalibMaxEpochs][n_bands], sized at creation
+  std::atomic<float> noise_floor{0.f};     // the estimate in force (0 until a calibration has finished)
   std::thread launcher;
   bool attached = false;                   // counted on the handle (crn_sense_set_bands refuses to change n_bands under a ring)
 };
+
+constexpr int kCalibMaxEpochs = 4096;      // crn_noise_floor_device uses at most this many
 
 // defined in crn_api.cpp
 extern "C" int crn_sense_cfg_of(crn_handle *h, crn_cfg *out);
@@ -130,6 +139,8 @@ std::string enqueue(crn_ingest *g, Batch &b) {
   // are readable 15-19 us sooner (tools/ring_rate: 89 -> 74 us; 8 epochs: 92 -> 73 us).  $CRN_INGEST_ZEROCOPY_BYTES: largest
   // batch handled so (0 = never)
   const bool zero_copy = in_bytes <= g->zero_copy_bytes;
+  // decided against whatever thresholds are in place now: while a calibration is collecting those are not the ones asked for
+  b.calibrating = g->calib_state.load(std::memory_order_acquire) != 0;
   hipError_t e = hipSuccess;
   if (!zero_copy) e = hipMemcpyAsync(b.d_iq, b.h_iq, in_bytes, hipMemcpyHostToDevice, g->stream);
   if (e != hipSuccess) return std::string("hipMemcpyAsync(H2D): ") + hipGetErrorString(e);
@@ -170,8 +181,30 @@ void collect(crn_ingest *g, const Batch &b, std::vector<crn_epoch_result> *out) 
     if (g->cfg.decide == CRN_DECIDE_ANN) std::memcpy(r.ann_out, ann + 3 * s, 3 * sizeof(double));
     std::memcpy(r.features, feat + (size_t)s * nb, nb * sizeof(float));
     std::memcpy(r.occupancy, occ + (size_t)s * nb, nb);
+    r.flags = b.calibrating ? CRN_EPOCH_CALIBRATION : 0;
+    r.noise_floor = b.calibrating ? 0.f : g->noise_floor.load(std::memory_order_relaxed);
     out->push_back(r);
   }
+}
+
+// Launcher thread, after a batch has come back: feed a calibration that is collecting; with the last epoch it wants, estimate the
+// noise floor on the device and put lambda x the estimate in as every band's threshold, ordered on the ring's stream — batches
+// launched from here on are decided against it (those already in flight keep their CRN_EPOCH_CALIBRATION mark).  Blocks this
+// thread for one small upload + reduction; never the pushing thread.  Returns an error message or "".
+std::string feed_calibration(crn_ingest *g, const std::vector<crn_epoch_result> &res) {
+  if (g->calib_state.load(std::memory_order_acquire) == 0) return "";
+  const int nb = g->cfg.n_bands;
+  for (const crn_epoch_result &r : res) {
+    if (g->calib_have >= g->calib_target) break;
+    std::memcpy(&g->calib_feat[(size_t)g->calib_have++ * nb], r.features, sizeof(float) * (size_t)nb);
+  }
+  if (g->calib_have < g->calib_target) return "";
+  float nf = 0.f;
+  const int rc = crn_sense_calibrate_thresholds(g->h, g->calib_feat.data(), g->calib_target, g->calib_lambda, &nf, g->stream);
+  g->calib_state.store(0, std::memory_order_release);   // also after a failure: the run goes on with the thresholds it had
+  if (rc != CRN_OK) return std::string("noise-floor calibration failed: ") + crn_last_error();
+  g->noise_floor.store(nf, std::memory_order_release);
+  return "";
 }
 
 // Give a batch back to the caller's thread (mu held).
@@ -226,10 +259,15 @@ void launcher_main(crn_ingest *g) {
     if (q == hipSuccess) {
       res.clear();
       collect(g, b, &res);
+      const std::string cal_err = feed_calibration(g, res);
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b.t_handoff).count();
       lk.lock();
       for (const crn_epoch_result &r : res) g->ready.push_back(r);
       g->n_epochs_ready += (int64_t)res.size();
+      if (!cal_err.empty() && g->err_code == CRN_OK) {
+        g->err_code = CRN_ERR_DEVICE;
+        g->err_msg = cal_err;
+      }
       g->lat_us_sum += us;
       if (us > g->lat_us_max) g->lat_us_max = us;
       release_batch(g, b);
@@ -353,6 +391,14 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   g->res_bytes = g->off_occ + align_up((size_t)g->C * nb, 256);
   g->open_slot.assign(n_streams, -1);
   g->seq.assign(n_streams, 0);
+  if (cfg.decide == CRN_DECIDE_THRESHOLD) {
+    // everything a later crn_ingest_calibrate needs: the launcher's feature buffer, the handle's pinned + device upload buffers
+    g->calib_feat.assign((size_t)kCalibMaxEpochs * nb, 0.f);
+    if (int rc = crn_sense_reserve_noise_floor(h)) {
+      crn_ingest_destroy(g);
+      return rc;
+    }
+  }
   hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     Batch &b = g->batch[i];
@@ -374,6 +420,27 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   (void)crn_sense_ring_count(h, +1);
   g->attached = true;
   *out = g;
+  return CRN_OK;
+}
+
+int crn_ingest_calibrate(crn_ingest *g, int32_t n_epochs, float lambda) {
+  if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");
+  if (g->cfg.decide != CRN_DECIDE_THRESHOLD) return crn::fail(CRN_ERR_STATE, "crn_ingest_calibrate: the handle does not decide by thresholds");
+  if (n_epochs < 1 || n_epochs > kCalibMaxEpochs) return crn::fail(CRN_ERR_ARG, "n_epochs must be in 1..4096");
+  if (!(lambda > 0.f)) return crn::fail(CRN_ERR_ARG, "lambda must be positive");
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->calib_state.load(std::memory_order_acquire) != 0) return crn::fail(CRN_ERR_STATE, "crn_ingest_calibrate: a calibration is already collecting");
+  g->calib_target = n_epochs;
+  g->calib_have = 0;
+  g->calib_lambda = lambda;
+  g->calib_state.store(1, std::memory_order_release);   // the launcher reads the three fields above only after it sees this
+  return CRN_OK;
+}
+
+int crn_ingest_noise_floor(crn_ingest *g, float *nf_out, int32_t *calibrating) {
+  if (!g || !nf_out) return crn::fail(CRN_ERR_ARG, "null argument");
+  *nf_out = g->noise_floor.load(std::memory_order_acquire);
+  if (calibrating) *calibrating = g->calib_state.load(std::memory_order_acquire);
   return CRN_OK;
 }
 

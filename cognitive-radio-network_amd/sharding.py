@@ -64,82 +64,31 @@ class OccupancyExchange:
         pass
 
 
-class TorchOccupancyExchange:
-    """Fallback only: the same double-buffered exchange through torch.distributed's RCCL backend, used by bench.py
-    when the C ABI's communicator cannot be set up on some rank (RCCL not loadable outside torch, say).  Same slot
-    logic: the all-gather of step i runs on a side stream behind an event, step i + 1's kernel starts at once."""
-
-    def __init__(self, epochs, n_bands, device, depth=2):
-        import torch
-        self._torch = torch
-        self.group = dist.new_group(backend="nccl") if dist.is_initialized() else None
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.epochs, self.n_bands, self.depth = epochs, n_bands, depth
-        self.local_bufs = [torch.empty(epochs, n_bands, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.all_bufs = [torch.empty(self.world * epochs, n_bands, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.side = torch.cuda.Stream(device=device)
-        self.ready = [torch.cuda.Event() for _ in range(depth)]
-        self.done = [torch.cuda.Event() for _ in range(depth)]
-        self.pending = [False] * depth
-
-    def local_ptr(self, i, stream):
-        s = i % self.depth
-        if self.pending[s]:
-            self._torch.cuda.current_stream().wait_event(self.done[s])
-            self.pending[s] = False
-        return self.local_bufs[s].data_ptr()
-
-    def exchange(self, i, stream):
-        torch, s = self._torch, i % self.depth
-        self.ready[s].record(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ready[s])
-            if self.group is not None:
-                dist.all_gather_into_tensor(self.all_bufs[s], self.local_bufs[s], group=self.group)
-            else:
-                self.all_bufs[s].copy_(self.local_bufs[s])
-            self.done[s].record(self.side)
-        self.pending[s] = True
-
-    def finish(self, stream):
-        for s in range(self.depth):
-            if self.pending[s]:
-                self._torch.cuda.current_stream().wait_event(self.done[s])
-                self.pending[s] = False
-
-    def gathered_host(self, i):
-        return self.all_bufs[i % self.depth].cpu().numpy()
-
-    def local_host(self, i):
-        return self.local_bufs[i % self.depth].cpu().numpy()
-
-    def close(self):
-        pass
-
-
 def make_device_exchange(epochs, n_bands, device_index, rank, world, depth=2):
-    """The C ABI's exchange; the torch fallback only if some rank cannot load / use RCCL through libcrnsense.  The
-    probe (every rank draws a throw-away unique id) is not collective, so a rank that fails cannot leave the others
-    waiting inside ncclCommInitRank.  Returns (exchange, description)."""
+    """The C ABI's exchange (crn_comm_*: RCCL loaded by libcrnsense itself) — the one backend this path has.  Every rank first
+    draws a throw-away unique id, which is not collective, and the ranks agree over the control group whether all of them could:
+    a rank that cannot load RCCL must not leave the others waiting inside ncclCommInitRank.  If any rank cannot, every rank
+    exits non-zero (the launcher then takes the job down); nothing falls back to another collective.
+    Returns (exchange, description)."""
+    import sys
     import torch
     import crnsense as cs
     ok, why = 1, ""
     try:
         cs.comm_unique_id()
-    except Exception as e:   # noqa: BLE001 — any failure means "not through the C ABI on this node"
+    except Exception as e:   # noqa: BLE001 — any failure means "RCCL cannot be used through the C ABI on this rank"
         ok, why = 0, str(e)
+    all_ok = ok
     if world > 1:
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
-    if ok:
-        return (DeviceOccupancyExchange(epochs, n_bands, device_index, rank, world, depth),
-                "RCCL all-gather of occupancy (crn_comm_*, side stream)")
-    import sys
-    print(f"sharding: rank {rank}: C-ABI communicator unavailable ({why[:200]}); falling back to torch.distributed's RCCL backend",
-          file=sys.stderr)
-    return (TorchOccupancyExchange(epochs, n_bands, torch.device("cuda", device_index), depth),
-            "RCCL all-gather of occupancy (FALLBACK: torch.distributed nccl backend, side stream; the C ABI's crn_comm_* could not load RCCL)")
+        all_ok = int(flag.item())
+    if not all_ok:
+        print(f"sharding: rank {rank}: " + (f"RCCL is not usable through crn_comm_* here ({why[:300]})" if not ok else
+                                            "another rank cannot load RCCL through crn_comm_*") + ": stopping (exit 3)", file=sys.stderr)
+        raise SystemExit(3)
+    return (DeviceOccupancyExchange(epochs, n_bands, device_index, rank, world, depth),
+            "RCCL all-gather of occupancy (crn_comm_*, side stream)")
 
 
 class DeviceOccupancyExchange:
@@ -176,6 +125,10 @@ class DeviceOccupancyExchange:
         import numpy as np
         raw = self.cs.device_to_host(self.comm.local_addr(i), self.epochs * self.n_bands)   # an accessor: no stream waits, slot state untouched
         return np.frombuffer(raw, dtype=np.uint8).reshape(self.epochs, self.n_bands)
+
+    def info(self):
+        """crn_comm_info: what RCCL itself reports for this rank's communicator."""
+        return self.comm.info()
 
     def close(self):
         self.comm.close()

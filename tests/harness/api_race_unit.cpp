@@ -1,0 +1,124 @@
+// TEST INFRASTRUCTURE: live updates of a handle against launches from another thread, without a GPU.  csrc/crn_api.cpp + crn_cfg.cpp +
+// crn_ingest.cpp as they are over tests/harness/fake_hip; built twice — ThreadSanitizer and AddressSanitizer (Makefile).
+//   thread A (the "CE thread"): pushes packets through a real ingest ring, whose launcher thread calls crn_sense_run_device
+//   thread B (the handle's owner): crn_sense_set_bands (same number of bands), crn_sense_set_thresholds, crn_sense_set_ann in a loop
+// The launch stand-in reads what a kernel reads through the pointers in its parameter block — the packed band table, the twiddles,
+// the thresholds — and checks that the plan it sees is ONE of the plans thread B installs, whole (never a mix of two, never a freed
+// slab: under ASan a stale pointer is a report, under TSan an unlocked field is one).  Reference for why this matters: execute()
+// runs with CE_mutex held while the rx thread keeps pushing (src/extensible_cognitive_radio.cpp:1310-1324, 1792-1803).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/crn_sense.h"
+#include "../../cognitive-radio-network_amd/csrc/crn_kernels.h"
+
+std::atomic<long long> g_fake_gpu_latency_ns{0};
+
+static std::atomic<long long> g_launches{0}, g_mixed{0}, g_plan_seen[2];
+
+namespace crn {
+hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipStream_t, bool) {
+  // the plan as a kernel would find it: band 1's first segment (lo, hi) from the packed table, the segment tables, the thresholds
+  const int sb = p.band_tab[1];                       // band_seg_begin[1]
+  const int lo = p.band_tab[96 + sb], hi = p.band_tab[256 + sb];
+  const int lo2 = p.seg_lo[p.band_seg_begin[1]], hi2 = p.seg_hi[p.band_seg_begin[1]];
+  float thr;
+  std::memcpy(&thr, &p.band_tab[416 + 1], sizeof(thr));
+  const float2 w = p.tw1[fft_len / 16 + 1];           // a twiddle from the same slab
+  const bool plan_a = lo == 8 && hi == 24, plan_b = lo == 40 && hi == 72;
+  if (!(plan_a || plan_b) || lo != lo2 || hi != hi2 || !(w.x > 0.9f) || !(thr == p.thresh[1])) g_mixed++;
+  g_plan_seen[plan_b ? 1 : 0]++;
+  for (long long e = 0; e < p.n_epochs; e++) {
+    if (p.decision) p.decision[e] = 1;
+    if (p.features) p.features[e * p.n_bands] = thr;
+  }
+  g_launches++;
+  return hipSuccess;
+}
+int sense_num_variants() { return 24; }
+unsigned sense_ref_acc_mask(int) { return 0xFFFFu; }
+bool sense_variant_available(int v) { return v == 0; }
+void sense_variant(int, int, int *a, int *b, int *c, int *d, int *e) { *a = *b = *c = *e = 1; *d = 0; }
+void sense_geometry(int fft_len, int, int *t, int *l, int *e) { *t = 256; *l = 0; *e = 256 / (fft_len / 16); }
+hipError_t launch_fft(const FftParams &, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_monitor(const MonitorParams &, hipStream_t) { return hipSuccess; }
+hipError_t launch_noise_floor(const float *feat, int n, int nb, float *scratch, hipStream_t) {
+  scratch[kNoiseFloorMaxEpochs] = feat[(long long)n * nb - 1];
+  return hipSuccess;
+}
+hipError_t launch_synth(const SynthParams &, hipStream_t) { return hipSuccess; }
+hipError_t launch_pack_sc16(const float *, long long, short *, float, hipStream_t) { return hipSuccess; }
+hipError_t launch_pu_pattern(const SynthParams &, hipStream_t) { return hipSuccess; }
+}  // namespace crn
+
+#define REQUIRE(c)                                                                \
+  do {                                                                            \
+    if (!(c)) {                                                                   \
+      std::fprintf(stderr, "api_race_unit: line %d: %s FAILED (%s)\n", __LINE__, #c, crn_last_error()); \
+      std::exit(1);                                                               \
+    }                                                                             \
+  } while (0)
+
+int main() {
+  crn_cfg cfg;
+  REQUIRE(crn_cfg_energy_scaled(&cfg, 1024, 4.0f) == CRN_OK);
+  const crn_band_seg plan_a[4] = {{600, 620, 0}, {8, 24, 1}, {110, 170, 2}, {378, 444, 3}};
+  const crn_band_seg plan_b[4] = {{600, 620, 0}, {40, 72, 1}, {110, 170, 2}, {378, 444, 3}};
+  std::memcpy(cfg.segs, plan_a, sizeof(plan_a));
+  cfg.n_segs = 4;
+  crn_handle *h = nullptr;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  crn_ingest *g = nullptr;
+  REQUIRE(crn_ingest_create(h, 2, 256, 2, &g) == CRN_OK);
+  REQUIRE(crn_sense_destroy(h) == CRN_ERR_STATE);      // a ring is attached: the handle stays (its launcher thread launches through it)
+
+  std::atomic<bool> stop{false};
+  std::thread pusher([&] {
+    std::vector<float> pkt(256 * 2, 0.5f);
+    crn_epoch_result r[8];
+    int32_t n = 0;
+    while (!stop.load()) {
+      for (int s = 0; s < 2; s++) {
+        const int rc = crn_ingest_push(g, s, pkt.data());
+        if (rc == CRN_ERR_BUSY) (void)crn_ingest_wait(g);
+        else if (rc != CRN_OK) { std::fprintf(stderr, "push: %s\n", crn_last_error()); std::exit(1); }
+      }
+      if (crn_ingest_poll(g, r, 8, &n) != CRN_OK) { std::fprintf(stderr, "poll: %s\n", crn_last_error()); std::exit(1); }
+    }
+  });
+  double w_ih[5][6], w_ho[6][4];
+  std::memset(w_ih, 0, sizeof(w_ih));
+  std::memset(w_ho, 0, sizeof(w_ho));
+  int updates = 0;
+  for (int it = 0; it < 400 || g_plan_seen[0].load() < 20 || g_plan_seen[1].load() < 20; it++) {
+    const bool b = it & 1;
+    REQUIRE(crn_sense_set_bands(h, b ? plan_b : plan_a, 4, 4, nullptr) == CRN_OK);
+    float thr[4] = {1.f + it, 2.f + it, 3.f + it, 4.f + it};
+    REQUIRE(crn_sense_set_thresholds(h, thr, 4, nullptr) == CRN_OK);       // (9 per pass of the staging ring's 8 slots: slots are reused)
+    REQUIRE(crn_sense_set_ann(h, w_ih, w_ho, 0.8, nullptr) == CRN_ERR_STATE);   // a threshold handle: refused under the lock too
+    crn_sense_stats st;
+    REQUIRE(crn_sense_get_stats(h, &st) == CRN_OK);
+    updates++;
+    if (it > 200000) break;
+    std::this_thread::yield();
+  }
+  // a change of the number of bands is refused while the ring is attached (its result buffers were sized for 4)
+  const crn_band_seg three[3] = {{600, 620, 0}, {8, 24, 1}, {110, 170, 2}};
+  const float thr3[3] = {1, 2, 3};
+  REQUIRE(crn_sense_set_bands(h, three, 3, 3, thr3) == CRN_ERR_STATE);
+  stop.store(true);
+  pusher.join();
+  REQUIRE(crn_ingest_drain(g) == CRN_OK);
+  REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+  REQUIRE(g_mixed.load() == 0 && g_launches.load() > 40 && g_plan_seen[0].load() >= 20 && g_plan_seen[1].load() >= 20);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);             // ... and goes once the ring is gone
+  std::printf("api_race_unit: %lld launches from the ring's launcher thread against %d band-plan + threshold updates (%lld saw plan A, %lld plan B, "
+              "0 saw a mix): ok\n", g_launches.load(), updates, g_plan_seen[0].load(), g_plan_seen[1].load());
+  return 0;
+}

@@ -62,6 +62,12 @@ static void rank_main(int rank, int world, const uint8_t *id, int64_t bytes, int
     for (int r = 0; r < world; r++)
       for (int64_t i = 0; i < bytes; i++) REQUIRE(all[(size_t)r * bytes + i] == (uint8_t)(100 * r + 10 * step + (i & 7)));   // rank order
   }
+  // what the collective itself says it is (the stand-in counts the ranks that joined its group)
+  crn_comm_info_t info;
+  REQUIRE(crn_comm_info(c, &info) == CRN_OK);
+  REQUIRE(info.nranks == world && info.rank == rank && info.depth == depth && info.bytes_per_rank == bytes);
+  REQUIRE(info.gathers == 3 * depth + 2 && info.rccl_version == 0 && strstr(info.library, "fake_rccl") != NULL);
+  REQUIRE(crn_comm_info(c, NULL) == CRN_ERR_ARG && crn_comm_info(NULL, &info) == CRN_ERR_ARG);
   uint8_t *p = NULL;
   REQUIRE(crn_comm_local(c, -1, NULL, &p) == CRN_ERR_ARG);
   REQUIRE(crn_comm_destroy(c) == CRN_OK);

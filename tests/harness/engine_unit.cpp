@@ -31,8 +31,6 @@ void CognitiveEngine::execute() {}
 
 // the rest of libcrnsense the engine links against, restated (the ring and crn_cfg_* are the real ones)
 static crn_cfg g_created_cfg;          // what the engine's constructor asked for
-static float g_thresholds_set[CRN_MAX_BANDS];
-static int g_threshold_updates = 0, g_synchronizes = 0;
 extern "C" {
 int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   *out = new crn_handle();
@@ -40,20 +38,6 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   g_created_cfg = *cfg;
   return CRN_OK;
 }
-// scan mode's start-up calibration: "the median band energy" of the stand-in's features is what the test put there
-int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs, float *nf_out) {
-  double s = 0;
-  for (int64_t e = 0; e < n_epochs; e++) s += features[e * h->cfg.n_bands + 1];   // (features[1] = the epoch's first sample)
-  *nf_out = (float)(s / (double)n_epochs);
-  return CRN_OK;
-}
-int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *) {
-  memcpy(g_thresholds_set, thresh, sizeof(float) * (size_t)n_bands);
-  memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
-  g_threshold_updates++;
-  return CRN_OK;
-}
-int crn_sense_synchronize(crn_handle *, void *) { g_synchronizes++; return CRN_OK; }
 int crn_sense_destroy(crn_handle *h) { delete h; return CRN_OK; }
 int crn_sense_reserve_host(crn_handle *, int64_t, int32_t) { return CRN_OK; }
 static int g_timing_requests = 0;
@@ -372,29 +356,66 @@ int main() {
     delete e;
   }
   // ---- -m scan: 64 equal bands, thresholds = lambda x the noise floor measured over the first -c epochs ----------------------------
-  {
+  // Enqueue-only form: the calibration belongs to the ring's launcher thread (crn_ingest_calibrate) — execute() is watched through
+  // ALL of it, calibrating epochs included, and makes not one HIP call.  Synchronous form (-a 0, offline): execute() launches and
+  // waits anyway; there the calibration is one allocation-free call (crn_sense_calibrate_thresholds after crn_sense_reserve_noise_floor).
+  for (int sync = 0; sync < 2; sync++) {
     ECRd ecr;
-    CE_Predictive_Node_GPU *e = make_engine(ecr, {"-g", "0", "-v", "0", "-n", "1024", "-m", "scan", "-c", "3", "-t", "5"});
+    std::vector<const char *> args = {"-g", "0", "-v", "0", "-n", "1024", "-m", "scan", "-c", "3", "-t", "5"};
+    if (sync) { args.push_back("-a"); args.push_back("0"); }
+    const int reserved0 = g_fake_nf_reserved.load();
+    CE_Predictive_Node_GPU *e = make_engine(ecr, args);
     REQUIRE(g_created_cfg.n_bands == 64 && g_created_cfg.hop == 512 && g_created_cfg.ref_band == -1 && g_created_cfg.frames_per_epoch == 8);
+    REQUIRE(g_fake_nf_reserved.load() > reserved0);           // the calibration's buffers were made by the constructor
     std::vector<std::complex<float> > buf(512);
     ecr.ce_usrp_rx_buffer = buf.data();
     ecr.ce_usrp_rx_buffer_length = 512;
+    g_watch_execute = !sync;
+    const long long hip_calls_before = fake_hip_calls_on_watched_threads.load();
     exec(ecr, ECRd::TIMEOUT);
     const int P = (7 * 512 + 1024 + 511) / 512;
-    const int updates0 = g_threshold_updates, syncs0 = g_synchronizes;
+    const int updates0 = g_fake_threshold_updates.load();
     const size_t mark = ecr.calls.size();
     for (int i = 0; i < 3; i++) feed_epoch(ecr, e, buf, 2, true, P, true);   // calibration epochs: a "decision" of 2 must NOT be acted on
     double f = 0;
     REQUIRE(tx_calls(ecr, mark, &f) == 0 && e->epochs_closed == 0 && e->epochs_calibrating == 3);
-    REQUIRE(g_threshold_updates == updates0 + 1 && g_synchronizes == syncs0 + 1);
-    REQUIRE(e->noise_floor == 2.0f && g_thresholds_set[0] == 10.0f && g_thresholds_set[63] == 10.0f);   // lambda x the estimate, every band
+    REQUIRE(g_fake_threshold_updates.load() == updates0 + 1);
+    REQUIRE(g_fake_thresholds_set[0] == 10.0f && g_fake_thresholds_set[63] == 10.0f);   // lambda x the estimate, every band
     for (int d = 0; d <= 3; d++) {   // afterwards the stand-in's occupied band (the one holding the channel's first bin) maps back to the channel
       const size_t m2 = feed_epoch(ecr, e, buf, d, true, P);
       REQUIRE(tx_calls(ecr, m2, &f) == (d == 0 ? 0 : 1) && (d == 0 || f == tx_for[d]));
+      REQUIRE(e->noise_floor == 2.0f);                         // (the enqueue-only form learns it with the first acted-on epoch)
     }
-    REQUIRE(g_threshold_updates == updates0 + 1);
+    REQUIRE(g_fake_threshold_updates.load() == updates0 + 1 && e->epochs_calibrating == 3 && e->epochs_closed == 4);
+    if (!sync) REQUIRE(fake_hip_calls_on_watched_threads.load() == hip_calls_before && fake_hip_waits_on_watched_threads.load() == 0);
+    g_watch_execute = false;
     e->release();
     delete e;
+  }
+  // ---- scan, a slow "GPU" and -b 2: epochs launched before the measured thresholds were in place are marked and not acted on ------
+  {
+    g_fake_gpu_latency_ns = 2000000;   // 2 ms per batch: further batches are launched while the last calibration batch is in flight
+    ECRd ecr;
+    CE_Predictive_Node_GPU *e = make_engine(ecr, {"-g", "0", "-v", "0", "-n", "1024", "-m", "scan", "-c", "2", "-t", "5", "-b", "1"});
+    std::vector<std::complex<float> > buf(512, std::complex<float>(3.f, 0.25f));
+    ecr.ce_usrp_rx_buffer = buf.data();
+    ecr.ce_usrp_rx_buffer_length = 512;
+    g_watch_execute = true;
+    const long long hip_calls_before = fake_hip_calls_on_watched_threads.load();
+    const long long t_end = fake_hip_now_ns() + 60000000;
+    while (fake_hip_now_ns() < t_end) exec(ecr, ecr.ce_sensing_flag ? ECRd::USRP_RX_SAMPS : ECRd::TIMEOUT);
+    g_watch_execute = false;
+    REQUIRE(fake_hip_calls_on_watched_threads.load() == hip_calls_before && fake_hip_waits_on_watched_threads.load() == 0);
+    // two epochs fed the estimate; whatever else was launched before the update is counted with them, and every epoch acted on
+    // was decided against the measured thresholds
+    REQUIRE(e->epochs_calibrating >= 2 && e->epochs_closed >= 1 && e->noise_floor == 3.0f);
+    double f = 0;
+    REQUIRE(tx_calls(ecr, 0, &f) == (int)e->epochs_closed && f == tx_for[3]);
+    printf("engine_unit: scan, slow GPU: %ld epochs marked calibration (2 fed the estimate), %ld acted on, HIP calls inside execute(): 0\n",
+           e->epochs_calibrating, e->epochs_closed);
+    e->release();
+    delete e;
+    g_fake_gpu_latency_ns = 0;
   }
   // ---- -w: the trainer's weights reach the engine through a file, at another FFT size ----------------------------------------------
   {

@@ -1,4 +1,4 @@
-// fake_rccl.cpp -> libfake_rccl.so — TEST INFRASTRUCTURE.  The five RCCL entry points csrc/crn_comm.cpp binds at run time,
+// fake_rccl.cpp -> libfake_rccl.so — TEST INFRASTRUCTURE.  The RCCL entry points csrc/crn_comm.cpp binds at run time,
 // for "ranks" that are THREADS of one CPU process (tests/harness/comm_unit.cpp, loaded through $CRN_RCCL_LIB): the all-gather
 // really places rank r's block at offset r * count of every rank's receive buffer, so the test sees what a world of two ranks
 // sees — rank order, slot addresses, byte counts — without a GPU.  Streams are ignored (the stand-in HIP calls are synchronous).
@@ -82,4 +82,9 @@ VIS ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t coun
 }
 VIS ncclResult_t ncclCommDestroy(Comm *c) { delete c; return ncclSuccess; }
 VIS const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl: invalid argument"; }
+// the queries behind crn_comm_info: the count is the number of ranks that really joined the group
+VIS ncclResult_t ncclCommCount(Comm *c, int *n) { std::lock_guard<std::mutex> lk(c->g->mu); *n = c->g->joined; return ncclSuccess; }
+VIS ncclResult_t ncclCommUserRank(Comm *c, int *r) { *r = c->rank; return ncclSuccess; }
+VIS ncclResult_t ncclCommCuDevice(Comm *, int *d) { *d = 0; return ncclSuccess; }
+VIS ncclResult_t ncclGetVersion(int *v) { *v = 0; return ncclSuccess; }   // 0: a stand-in, no RCCL release
 }

@@ -1,4 +1,4 @@
-// fake_rccl_mp.cpp -> libfake_rccl_mp.so — TEST INFRASTRUCTURE.  The five RCCL entry points csrc/crn_comm.cpp binds at run time, for
+// fake_rccl_mp.cpp -> libfake_rccl_mp.so — TEST INFRASTRUCTURE.  The RCCL entry points csrc/crn_comm.cpp binds at run time, for
 // ranks that are PROCESSES sharing one GPU box ($CRN_RCCL_LIB; tests/test_bench_cli.py runs `torch.distributed.run --nproc-per-node 2
 // bench.py --gpus 2` with it): real RCCL refuses two ranks on one device, and the pool hands out one GPU, so this is how bench.py's
 // whole N > 1 flow (gloo control plane, unique-id broadcast, sharding, barriers, max-over-ranks timing, the gathered-vector check)
@@ -83,4 +83,9 @@ VIS ncclResult_t ncclCommDestroy(Comm *c) {
   return ncclSuccess;
 }
 VIS const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake rccl (multi-process): error"; }
+// the queries behind crn_comm_info: the count is the number of processes that really attached to the segment, not nranks echoed
+VIS ncclResult_t ncclCommCount(Comm *c, int *n) { *n = __atomic_load_n(&c->sh->joined, __ATOMIC_ACQUIRE); return ncclSuccess; }
+VIS ncclResult_t ncclCommUserRank(Comm *c, int *r) { *r = c->rank; return ncclSuccess; }
+VIS ncclResult_t ncclCommCuDevice(Comm *, int *d) { return hipGetDevice(d) == hipSuccess ? ncclSuccess : ncclSystemError; }
+VIS ncclResult_t ncclGetVersion(int *v) { *v = 0; return ncclSuccess; }   // 0: a stand-in, no RCCL release
 }

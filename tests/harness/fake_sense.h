@@ -31,6 +31,24 @@ struct crn_handle { crn_cfg cfg; };
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
 static std::atomic<int> g_fake_rings_attached{0};
 int crn_sense_ring_count(crn_handle *, int delta) { g_fake_rings_attached += delta; return CRN_OK; }
+// calibration (crn_ingest_calibrate -> the ring's launcher thread -> these two): "the median band energy" of the stand-in's features
+// is the mean of features[1] (the epochs' first samples: what the test put there).  The stand-in makes the kinds of HIP call the
+// real one makes — an upload, a wait — through the fake runtime, so a test that watches a thread sees them if they run on it.
+static float g_fake_thresholds_set[CRN_MAX_BANDS];
+static std::atomic<int> g_fake_threshold_updates{0}, g_fake_nf_reserved{0};
+int crn_sense_reserve_noise_floor(crn_handle *) { g_fake_nf_reserved++; return CRN_OK; }
+int crn_sense_calibrate_thresholds(crn_handle *h, const float *features, int64_t n_epochs, float lambda, float *nf_out, void *stream) {
+  if (!g_fake_nf_reserved.load()) return crn::fail(CRN_ERR_STATE, "crn_sense_calibrate_thresholds without crn_sense_reserve_noise_floor");
+  static float upload[4096 * CRN_MAX_BANDS];
+  (void)hipMemcpyAsync(upload, features, sizeof(float) * (size_t)n_epochs * h->cfg.n_bands, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+  (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  double s = 0;
+  for (int64_t e = 0; e < n_epochs; e++) s += upload[e * h->cfg.n_bands + 1];
+  *nf_out = (float)(s / (double)n_epochs);
+  for (int b = 0; b < h->cfg.n_bands; b++) g_fake_thresholds_set[b] = h->cfg.thresh[b] = lambda * *nf_out;
+  g_fake_threshold_updates++;
+  return CRN_OK;
+}
 static std::atomic<long long> g_fake_launches{0};
 static std::atomic<int> g_fake_last_L{0};
 static std::atomic<long long> g_fake_last_stride{0};

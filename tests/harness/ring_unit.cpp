@@ -378,6 +378,61 @@ int main() {
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
     g_fake_gpu_latency_ns = 0;
   }
+  // noise-floor calibration on the launcher thread (crn_ingest_calibrate): posted by this thread without a HIP call, carried out
+  // by the launcher after the n-th epoch came back; every epoch launched before the thresholds landed is marked, the first
+  // unmarked one carries the estimate; a slow "GPU" makes batches overlap the calibration
+  for (int slow = 0; slow < 2; slow++) {
+    crn_handle ht;
+    memset(&ht, 0, sizeof(ht));
+    ht.cfg.fft_len = ht.cfg.hop = 512;
+    ht.cfg.frames_per_epoch = 10;
+    ht.cfg.n_bands = 8;
+    ht.cfg.decide = CRN_DECIDE_THRESHOLD;
+    g_fake_gpu_latency_ns = slow ? 1000000 : 0;
+    REQUIRE(crn_ingest_calibrate(g = NULL, 4, 2.f) == CRN_ERR_ARG);
+    const int reserved0 = g_fake_nf_reserved.load(), updates0 = g_fake_threshold_updates.load();
+    REQUIRE(crn_ingest_create(&ht, 1, 64, 1, &g) == CRN_OK);
+    REQUIRE(g_fake_nf_reserved.load() == reserved0 + 1);                      // buffers made at creation, not by the request
+    REQUIRE(crn_ingest_calibrate(g, 0, 2.f) == CRN_ERR_ARG && crn_ingest_calibrate(g, 4, 0.f) == CRN_ERR_ARG);
+    float nf = -1.f;
+    int32_t busy = -1;
+    REQUIRE(crn_ingest_noise_floor(g, &nf, &busy) == CRN_OK && nf == 0.f && busy == 0);
+    fake_hip_watch_thread = true;
+    const long long calls0 = fake_hip_calls_on_watched_threads.load();
+    REQUIRE(crn_ingest_calibrate(g, 4, 2.f) == CRN_OK);
+    REQUIRE(fake_hip_calls_on_watched_threads.load() == calls0);               // only a request: no HIP call on the posting thread
+    fake_hip_watch_thread = false;
+    REQUIRE(crn_ingest_calibrate(g, 4, 2.f) == CRN_ERR_STATE);                 // one at a time
+    std::vector<crn_epoch_result> all;
+    for (long e = 0; e < 12; e++)
+      for (int p = 0; p < 10; p++) {
+        std::vector<float> pk((size_t)64 * 2, (float)(e + 1));                 // features[1] of epoch e = e + 1
+        int rc;
+        while ((rc = crn_ingest_push(g, 0, pk.data())) == CRN_ERR_BUSY) { REQUIRE(crn_ingest_wait(g) == CRN_OK); collect(g, &all); }
+        REQUIRE(rc == CRN_OK);
+      }
+    REQUIRE(crn_ingest_drain(g) == CRN_OK);
+    collect(g, &all);
+    REQUIRE(all.size() == 12 && g_fake_threshold_updates.load() == updates0 + 1);
+    REQUIRE(crn_ingest_noise_floor(g, &nf, &busy) == CRN_OK && nf == 2.5f && busy == 0);   // mean of 1, 2, 3, 4
+    REQUIRE(g_fake_thresholds_set[0] == 5.0f && g_fake_thresholds_set[7] == 5.0f && ht.cfg.thresh[3] == 5.0f);
+    size_t marked = 0;
+    while (marked < all.size() && (all[marked].flags & CRN_EPOCH_CALIBRATION)) marked++;
+    REQUIRE(marked >= 4 && marked < 12);                                         // the four that fed it (+ any launched before it landed)
+    if (!slow) REQUIRE(marked <= 5);
+    for (size_t i = 0; i < all.size(); i++) {
+      REQUIRE(all[i].epoch_seq == (long)i);
+      REQUIRE(((all[i].flags & CRN_EPOCH_CALIBRATION) != 0) == (i < marked));    // marked epochs first, none after the update
+      REQUIRE(all[i].noise_floor == (i < marked ? 0.f : 2.5f));
+    }
+    REQUIRE(crn_ingest_calibrate(g, 2, 3.f) == CRN_OK);                          // again later: re-calibration
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    // a handle that decides by the network has nothing to calibrate
+    REQUIRE(crn_ingest_create(&h, 1, 64, 1, &g) == CRN_OK);
+    REQUIRE(crn_ingest_calibrate(g, 4, 2.f) == CRN_ERR_STATE);
+    REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+    g_fake_gpu_latency_ns = 0;
+  }
   REQUIRE(g_fake_rings_attached.load() == 0);   // every ring that attached to its handle detached again
   printf("ring_unit: ok\n");
   return 0;

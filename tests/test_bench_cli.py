@@ -44,17 +44,16 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline(built):
 
 
 def test_bench_default_batch_with_every_alt_leg_and_the_cpu_check(built):
-    """The driver's shape: the default 8.75 GiB batch, so that the config.alt legs run (2 GiB batch, unpruned kernel, 16-bit radio
-    samples) — and the CPU sample check after them still reads the headline launch's results, not a leg's."""
+    """The driver's shape: the default 8.75 GiB batch, so that the config.alt legs run (SURVEY §8(d)'s 2 GiB batch on one and on two
+    streams, the unpruned kernel) — and the CPU sample check after them still reads the headline launch's results, not a leg's.
+    Nothing outside north_star rides in the default line: no 16-bit-input or wire-format legs (--wire-format is opt-in)."""
     d = _run("--cpu-epochs", "64", epochs=())
     alt = d["config"]["alt"]
-    assert set(alt) == {"cfgH_2GiB_batch", "cfgH_2GiB_batch_two_streams", "unpruned", "adc16_input", "wire_format_sc16"}
+    assert set(alt) == {"cfgH_2GiB_batch", "cfgH_2GiB_batch_two_streams", "unpruned"}
     two = alt.pop("cfgH_2GiB_batch_two_streams")
     assert two["outputs_identical_across_streams"] and two["launches"] == 60 and 0.3 < two["frac"] < 1.0
     assert two["bytes_per_step"] == alt["cfgH_2GiB_batch"]["bytes_per_step"]
     assert alt["cfgH_2GiB_batch"]["kernel_ms_min"] <= alt["cfgH_2GiB_batch"]["kernel_ms_mean"]
-    assert alt["wire_format_sc16"]["bytes_per_step"] * 2 == alt["adc16_input"]["bytes_per_step"]
-    assert alt["wire_format_sc16"]["Msamples/s"] > alt["adc16_input"]["Msamples/s"]
     for leg in alt.values():
         assert 0.3 < leg["frac"] < 1.0 and leg["kernel_ms_mean"] > 0
     assert alt["cfgH_2GiB_batch"]["bytes_per_step"] == 6553 * 40960 * 8
@@ -78,34 +77,28 @@ def test_bench_collective_path_on_one_gpu(built, mode):
     d = _run("--cpu-epochs", "0", "--force-collective", *mode)
     assert "RCCL all-gather of occupancy" in d["config"]["parallelism"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    # one real RCCL rank: the line says what RCCL itself reports for the communicator the gathers ran on
+    r = d["config"]["rccl"]
+    assert r["nranks"] == 1 and r["user_ranks"] == [0] and r["version"] > 20000 and "rccl" in r["library"] and r["rank0_device"] == 0
+    assert r["gathers_per_rank"][0] >= d["steps"] and d["roofline"]["per_rank"]["slowest_rank"] == 0
     if "welch" in mode or "scan" in mode:
         assert d["roofline_valu"]["bound"] == "valu" and 0 < d["roofline_valu"]["frac"] < 1
         assert "Welch" in d["metric"]
 
 
-def test_bench_falls_back_to_torch_rccl_when_the_c_abi_cannot_load_rccl(built):
-    """bench.py's N > 1 path uses the C ABI's communicator; if RCCL cannot be loaded through libcrnsense on some rank
-    (the probe is forced to fail here) the ranks agree, over the control group, to use torch.distributed's RCCL backend
-    instead of hanging or dying — and say so in config.parallelism."""
+def test_bench_ranks_stop_together_when_rccl_cannot_be_loaded(built):
+    """The occupancy exchange has ONE backend — RCCL through the C ABI's crn_comm_*.  A job whose ranks cannot load it ($CRN_RCCL_LIB
+    names a file that is not there) agrees on that over the control group and every rank exits non-zero: no hang inside
+    ncclCommInitRank, no other collective backend, no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CRN_RCCL_LIB="/nonexistent/librccl.so", HIP_VISIBLE_DEVICES="0")
+    from test_comm import _run_group
+    out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs", "256",
+                      "--cpu-epochs", "0"], 300, env, cwd=ROOT)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert "RCCL is not usable through crn_comm_*" in out.stderr or "cannot load RCCL" in out.stderr
     import sharding
-    import torch
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    real = cs.comm_unique_id
-    try:
-        cs.comm_unique_id = lambda: (_ for _ in ()).throw(cs.CrnError("forced: RCCL not loadable"))
-        ex, kind = sharding.make_device_exchange(8, 4, 0, 0, 1)
-    finally:
-        cs.comm_unique_id = real
-    assert "FALLBACK" in kind and isinstance(ex, sharding.TorchOccupancyExchange)
-    stream = torch.cuda.current_stream().cuda_stream
-    for i in range(3):
-        ex.local_bufs[i % 2].fill_(i + 1)
-        assert ex.local_ptr(i, stream) == ex.local_bufs[i % 2].data_ptr()
-        ex.exchange(i, stream)
-    ex.finish(stream)
-    torch.cuda.synchronize()
-    assert (ex.gathered_host(2) == 3).all()
+    assert not hasattr(sharding, "TorchOccupancyExchange")
 
 
 def test_bench_wire_format_mode(built):
@@ -141,8 +134,8 @@ def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["epochs_per_gpu"] == 2048
         assert d["config"]["parallelism"].startswith("stream-sharded x2") and "crn_comm_" in d["config"]["parallelism"]
-        assert "FALLBACK" not in d["config"]["parallelism"] and d["cpu_baseline"] is None
-        assert d["value"] > 0 and d["ms_per_step"] > 0
+        assert d["cpu_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0
+        assert d["config"]["rccl"]["nranks"] == 2 and d["config"]["rccl"]["user_ranks"] == [0, 1]
 
 
 def _self_launched(n, *extra, epochs="512", timeout=600):
@@ -164,21 +157,32 @@ def _self_launched(n, *extra, epochs="512", timeout=600):
 def test_bench_self_launches_two_ranks_without_a_launcher(built):
     d = _self_launched(2)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("stream-sharded x2")
-    assert "crn_comm_" in d["config"]["parallelism"] and "FALLBACK" not in d["config"]["parallelism"]
+    assert "crn_comm_" in d["config"]["parallelism"] and d["config"]["rccl"]["nranks"] == 2
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
 @pytest.mark.parametrize("mode", [[], ["--mode", "scan"]])
-def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode):
+def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode, scaling):
     """BASELINE.json configs[4] as the driver will start it (`python3 bench.py --gpus 8 ...`), rehearsed with the eight ranks sharing
     the one GPU: bench.py starts torch.distributed.run itself before it touches the GPU, gloo control plane, RCCL unique id from
     rank 0 through the C ABI, streams sharded eight ways, crn_comm_* slots, the barriers and the max-over-ranks timing; EVERY rank
     checks that its own block sits unchanged at its place in the gathered vector (a mismatch on any rank makes the launcher, and so
     the parent, exit non-zero) and rank 0's single JSON line is relayed."""
-    d = _self_launched(8, *mode, epochs="1024")
-    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["epochs_per_gpu"] == 1024
+    # weak: 1024 epochs on every rank.  strong: 8192 epochs in all, split eight ways — a share far below 4 GiB, so every rank
+    # alternates its launches between two streams (four exchange slots)
+    d = _self_launched(8, *mode, "--scaling", scaling, epochs="1024" if scaling == "weak" else "8192")
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["epochs_per_gpu"] == 1024
+    assert d["config"]["epochs_per_step_all_gpus"] == 8192 and d["config"]["streams_per_gpu"] == (2 if scaling == "strong" else 1)
     assert d["config"]["parallelism"].startswith("stream-sharded x8") and "crn_comm_" in d["config"]["parallelism"]
-    assert "FALLBACK" not in d["config"]["parallelism"] and d["cpu_baseline"] is None
-    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
+    assert d["cpu_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
+    # the line proves what the collective saw: eight ranks, every one of them counted eight, in rank order, each with its gathers
+    r = d["config"]["rccl"]
+    assert r["nranks"] == 8 and r["nranks_seen_by_every_rank"] == [8] and r["user_ranks"] == list(range(8)) and len(r["devices"]) == 8
+    assert "fake_rccl_mp" in r["library"] and r["version"] == 0          # (the stand-in says so)
+    pr = d["roofline"]["per_rank"]
+    assert len(pr["kernel_ms_mean"]) == 8 and pr["kernel_ms_mean_min"] <= pr["kernel_ms_mean_max"] and 0 <= pr["slowest_rank"] < 8
+    assert 0 < pr["frac_slowest_rank"] <= pr["frac_fastest_rank"]
+    assert ("two streams" in d["roofline"]["events"]) == (scaling == "strong")
     if mode:
         assert "cfg4" in d["config"]["workload"]
 

@@ -60,6 +60,19 @@ def test_api_host_logic_tables_and_launch_geometry(built):
     assert "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[:3000]
 
 
+def test_live_updates_against_the_ring_launcher_thread(built):
+    """tests/harness/api_race_unit.cpp: one thread pushes packets through a real ingest ring (whose launcher thread launches through
+    the handle) while another swaps the band plan (same number of bands) and the thresholds in a loop — crn_api.cpp + crn_ingest.cpp
+    as they are over the host-only HIP stand-in.  Every launch must see one plan, whole; crn_sense_destroy is refused while the ring is
+    attached.  ThreadSanitizer build, then AddressSanitizer + UBSan (a launch that kept a pointer into a freed table slab is a report)."""
+    for name in ("api_race_unit", "api_race_unit_asan"):
+        exe = os.path.join(HARNESS, name)
+        subprocess.check_call(["make", "-C", HARNESS, exe], stdout=subprocess.DEVNULL)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+        assert out.returncode == 0 and "0 saw a mix): ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        assert "WARNING: ThreadSanitizer" not in out.stderr and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[:3000]
+
+
 def test_ring_and_engine_under_address_and_ub_sanitizers(built):
     """The same two programs built with -fsanitize=address,undefined (they cannot share a build with ThreadSanitizer): the pinned
     buffers' slot arithmetic, the carry-over copies of open epochs, the byte-sized layout of the wire-format ring."""
