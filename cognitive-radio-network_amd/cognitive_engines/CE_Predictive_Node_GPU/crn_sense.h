@@ -341,8 +341,8 @@ CRN_API int crn_ingest_destroy(crn_ingest *g);
  *           crn_comm_allgather(c, i, stream)     -> returns at once; the gather runs on the side stream
  *           ... crn_comm_gathered(c, i, &all)    valid once `stream` has passed crn_comm_finish / the
  *                                                crn_comm_local of step i + depth
- * RCCL is loaded at run time by crn_comm_unique_id / crn_comm_create (librccl.so.1, or $CRN_RCCL_LIB):
- * single-GPU users of libcrnsense do not need it. */
+ * RCCL is loaded at run time by crn_comm_unique_id / crn_comm_create — librccl.so.1, or exactly the library $CRN_RCCL_LIB names
+ * (if that does not load the calls fail: no other RCCL is tried) — so single-GPU users of libcrnsense do not need it. */
 typedef struct crn_comm crn_comm;
 #define CRN_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
 

@@ -53,8 +53,11 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // $CRN_RCCL_LIB, when set, is THE library: a name that does not load is an error, not a hint (a job told to use one RCCL must
+    // not quietly run over another)
     const char *env = std::getenv("CRN_RCCL_LIB");
-    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const bool forced = env && *env;
+    const char *names[] = {env, forced ? nullptr : "librccl.so.1", forced ? nullptr : "librccl.so", forced ? nullptr : "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
       if (!n || !*n) continue;
       r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -86,6 +86,18 @@ def test_bench_collective_path_on_one_gpu(built, mode):
         assert "Welch" in d["metric"]
 
 
+def test_bench_two_streams_per_gpu(built):
+    """--two-streams (what --scaling strong selects by itself for shares under 4 GiB): launches alternate between two streams with an
+    output set each and four exchange slots; the roofline is priced from the span over both streams; the last launch's outputs still
+    pass the oracle check and the gathered-vector check."""
+    d = _run("--cpu-epochs", "0", "--two-streams", "--force-collective")
+    assert d["config"]["streams_per_gpu"] == 2 and "two streams" in d["roofline"]["events"]
+    assert d["config"]["rccl"]["nranks"] == 1 and d["config"]["rccl"]["gathers_per_rank"][0] >= d["steps"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel_ms_min"] == d["roofline"]["kernel_ms_max"]   # one span figure
+    d = _run("--cpu-epochs", "0", "--two-streams", "--mode", "welch")
+    assert d["config"]["streams_per_gpu"] == 2 and d["value"] > 0
+
+
 def test_bench_ranks_stop_together_when_rccl_cannot_be_loaded(built):
     """The occupancy exchange has ONE backend — RCCL through the C ABI's crn_comm_*.  A job whose ranks cannot load it ($CRN_RCCL_LIB
     names a file that is not there) agrees on that over the control group and every rank exits non-zero: no hang inside

@@ -9,7 +9,8 @@ an epoch whose output lands that close to the compare can fall on the other side
   ANN (N = 512, reference mode): per channel, bisect the amplitude of a carrier at the channel's centre bin (over a fixed AWGN
       realisation) until the oracle's Output[k] straddles 0.8; then >= 10 000 amplitudes, log-spaced in |delta| from 1e-8 to 1e-4 on
       both sides of the crossing (relative amplitude), through the GPU and the oracle.
-  thresholds (N = 1024 and 4096, energy mode, thr relative to the noise-floor band): the same around feature / (thr x ref) = 1.
+  thresholds (N = 1024 and 4096, energy mode, thr relative to the noise-floor band; and the Welch scan's plan: N = 4096, Hann,
+      50 % overlap, 64 bands, absolute thresholds, dense epochs through the streaming kernel): the same around feature / thr = 1.
 
 and reports, per channel and size, the widest distance from the compare at which the two disagreed.  The table goes to
 $CRN_EVIDENCE_DIR/decision_band.txt (committed as profiles/r04_decision_band.txt); tests/parity_policy.py carries the measured widths
@@ -148,6 +149,59 @@ def test_decision_disagreement_band_is_measured_and_inside_the_margins(built):
             worst_thr = max(worst_thr, band)
             assert not (differ & (dist > pol.THRESHOLD_MARGIN)).any(), f"N = {n_fft} CH{ch}: occupancy differs outside the margin {pol.THRESHOLD_MARGIN:g}"
         sensor.close()
+    # ---- the Welch scan's plan (N = 4096, Hann, hop N/2, K = 8, 64 equal bands, absolute thresholds): the streaming kernel with the
+    # window folded into pass 1 and band sums by DPP — another summation order again.  Dense epochs (consecutive epochs share half a
+    # frame), so an epoch's ratio also sees its neighbour's amplitude: both sides read the same bytes, which is all the comparison needs.
+    cfg = cs.cfg_welch(4096, 8, 64)
+    N, K, hop = cfg.fft_len, cfg.frames_per_epoch, cfg.hop
+    nf = (N / 64) * N * 1e-6 * 0.375
+    for b in range(64):
+        cfg.thresh[b] = 4.0 * nf
+    sensor = cs.Sensor(cfg)
+    lines += ["", "thresholds, N = 4096 Welch scan plan (Hann, 50 % overlap, 64 bands): compare feature_b > thr_b (fp32, absolute)",
+              "  band  bin   amplitude*   epochs  differ  band |E/thr-1|  widest |delta| differing  closest sample |E/thr-1|  max feature rel. diff  ratio range swept"]
+    cores = os.cpu_count() or 1
+    for b in (5, 37):
+        rng = np.random.default_rng(9300 + b)
+        sig = np.sqrt(1e-6 / 2)
+        spe = K * hop
+        block = (rng.normal(0, sig, spe) + 1j * rng.normal(0, sig, spe)).astype(np.complex64).astype(np.complex128)
+        k = 64 * b + 32
+
+        def stream(amps, block=block, k=k):
+            n = len(amps)
+            total = n * spe + (N - hop)
+            idx = np.arange(total)
+            a = np.repeat(np.asarray(amps, np.float64), spe)
+            a = np.concatenate([a, np.full(N - hop, a[-1])])
+            x = np.tile(block, n + 1)[:total] + a * np.exp(2j * np.pi * k * (idx % N) / N + 0.3j)
+            return x.astype(np.complex64).view(np.float32).reshape(-1)
+
+        def past(a, b=b):
+            w = orc.run(cfg, stream([a] * 3), 3)
+            return 0.5 if w["occupancy"][1, b] else -0.5
+        a_star = _bisect(past, 0.0, 0.1)
+        amps = _sweep_amplitudes(a_star)
+        got, want = [], []
+        for i in range(0, len(amps), 2500):
+            iq = stream(amps[i:i + 2500])
+            n = len(amps[i:i + 2500])
+            got.append(sensor.run_host(iq, n))
+            want.append(orc.run(cfg, iq, n, n_threads=cores))
+        got = {kk: np.concatenate([r[kk] for r in got]) for kk in got[0]}
+        want = {kk: np.concatenate([r[kk] for r in want]) for kk in want[0]}
+        r = want["features"][:, b].astype(np.float64) / np.float64(np.float32(cfg.thresh[b]))
+        differ = (got["occupancy"] != want["occupancy"]).any(axis=1) | (got["decision"] != want["decision"])
+        dist = np.abs(r - 1.0)
+        band = float(dist[differ].max()) if differ.any() else 0.0
+        wide = float(np.abs(amps / a_star - 1)[differ].max()) if differ.any() else 0.0
+        assert not want["occupancy"][:N_SWEEP // 10, b].any() and want["occupancy"][-(N_SWEEP // 10):, b].all(), "the sweep does not straddle the compare"
+        rel = np.abs(got["features"] - want["features"]) / np.abs(want["features"])
+        lines.append(f"  {b:3d}  {k:4d}  {a_star:.6e}  {amps.size}  {int(differ.sum()):5d}   {band:.3e}       {wide:.3e}                 {dist.min():.3e}"
+                     f"                {rel.max():.3e}              {r.min():.7f} .. {r.max():.7f}")
+        worst_thr = max(worst_thr, band)
+        assert not (differ & (dist > pol.THRESHOLD_MARGIN)).any(), f"Welch band {b}: occupancy differs outside the margin {pol.THRESHOLD_MARGIN:g}"
+    sensor.close()
     lines += ["", f"widest band: ANN |O - 0.8| = {worst_ann:.3e}  (parity_policy.ANN_DISAGREEMENT_BAND = {pol.ANN_DISAGREEMENT_BAND:g}, margin {pol.ANN_MARGIN:g});  "
                   f"thresholds |E/thr - 1| = {worst_thr:.3e}  (parity_policy.THRESHOLD_DISAGREEMENT_BAND = {pol.THRESHOLD_DISAGREEMENT_BAND:g}, margin {pol.THRESHOLD_MARGIN:g})"]
     print("\n".join(lines))

@@ -10,12 +10,15 @@ import pytest
 
 import crnsense as cs
 import oracle_py as orc
+import parity_policy as pol
 
 pytestmark = pytest.mark.gpu
 
 TOTAL_EPOCHS = 1_048_576
 CHUNK = 131_072
-MARGIN = 1e-3          # |O[k] - 0.8| below this = near-threshold (CE_Predictive_Node.cpp:246-256 compare)
+# |O[k] - 0.8| below this = near-threshold (CE_Predictive_Node.cpp:246-256 compare): 10 x the width of the band inside which GPU and
+# CPU path were measured to disagree (tests/test_decision_band.py, tests/parity_policy.py) — 6e-6, not the 1e-3 of earlier rounds
+MARGIN = pol.ANN_MARGIN
 
 
 def test_cfg3_million_epochs_decisions_bit_exact(built):

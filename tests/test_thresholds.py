@@ -8,6 +8,7 @@ import pytest
 
 import crnsense as cs
 import oracle_py as orc
+import parity_policy as pol
 
 
 def _lower_median(a, axis=None):
@@ -85,7 +86,7 @@ def test_calibrated_thresholds_match_oracle_and_find_the_driven_band(built):
     torch.cuda.synchronize()
     want = orc.run(sn.cfg, iq.cpu().numpy(), n)                        # sn.cfg carries the new thresholds
     got = occ.cpu().numpy()
-    safe = np.abs(want["features"] / (4.0 * nf) - 1) > 1e-4
+    safe = np.abs(want["features"] / (4.0 * nf) - 1) > pol.THRESHOLD_MARGIN   # 10 x the measured disagreement band (tests/test_decision_band.py)
     assert np.array_equal(got[safe], want["occupancy"][safe])
     t = truth.cpu().numpy()
     driven = t > 0
