@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 per-launch events, against the 8 TB/s peak; min / median / max per launch alongside
   roofline_valu (windowed / Welch modes, which are VALU-issue-bound) algorithmic flops against the fp32
                 vector peak, plus the measured VALU-busy fraction at the measured clock from the committed
-                counter passes of the same command (profiles/r03_valu_counters.json)
+                counter passes of the same command (profiles/valu_counters.json)
   config.alt    (N = 1, headline workload) the same kernel on SURVEY.md §8(d)'s 2 GiB batch, and the
                 kernel any other band table / a spectrum request gets (no row pruning)
   cpu_baseline  the oracle (CPU restatement of the reference path, built -O2 -march=native on this box)
@@ -210,7 +210,7 @@ def main():
                     help="do not measure roofline.traffic with rocprofv3 counter passes of a short child run (N = 1 only); "
                          "use the committed figure instead")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
-    ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "r03_valu_counters.json"))
+    ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "valu_counters.json"))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -284,7 +284,7 @@ def main():
     n_samples = cs.samples_needed(cfg, E)
     lo, hi = shard(E * world, rank, world)
     assert hi - lo == E
-    # a small share per GPU: ramp + drain are > 9 % of a 1 GiB launch (profiles/r03_batch_timeline.txt); two streams overlap them
+    # a small share per GPU: ramp + drain are > 9 % of a 1 GiB launch (measured with in-kernel time stamps in round 3); two streams overlap them
     two_streams = args.two_streams or (args.scaling == "strong" and E * spe * 8 < (4 << 30))
 
     sensor = cs.Sensor(cfg)

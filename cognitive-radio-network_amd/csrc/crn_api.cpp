@@ -561,7 +561,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // half-frame is the previous span's last — so its spans are made long: ~256 frames per big workgroup while at least ~2.7
     // rounds of them remain over the 768 slots (3 workgroups per CU), a quarter of that per tail workgroup, one tail
     // workgroup per slot.  At K = 8 that is 32 epochs / 8 epochs / 6144 epochs: traffic 1.005 x the algorithmic bytes instead
-    // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r03_welch_spans.txt).
+    // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r04_welch_spans.txt).
     if (c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop) {
       const int64_t slots = slots3;
       epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups * 3 / (8 * slots));   // >= 2.67 rounds of them

@@ -92,7 +92,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
 #endif
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
-  // window registers fewer; the A/B numbers are in DESIGN.md §5)
+  // window registers fewer; the A/B numbers are in docs/history/DESIGN_r03.md §5)
   // (variants 2 and 23 are forms of the plain kernel: a windowed handle that selects them runs its default, not the table-window form)
   if (win && !mag && p.hann_sym && p.L == Geo<R3>::N &&
       (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant || variant == 2 || variant == 23)) {

@@ -6,7 +6,7 @@ Per bin       |E - E64| <= bound * max(E64, 1e-3 * mean_k E64), E = the K-frame 
               bound = 1e-5 up to +30 dB of in-band SNR of the driven channel at every size; above that the error follows the
               carrier's amplitude (fp32 dynamic range next to a strong carrier, whatever the factorisation: the radix-2 CPU
               restatement is 1.3-2x further off) and the bound is the fitted line snr_bound() below
-              (measured table: tests/test_gpu_parity.py::test_per_bin_error_against_in_band_snr, profiles/r03_per_bin_error_vs_snr.txt).
+              (measured table: tests/test_gpu_parity.py::test_per_bin_error_against_in_band_snr, profiles/r04_per_bin_error_vs_snr.txt).
 Features      relative 1e-5 against the oracle.
 Decisions     identical to the oracle's for every epoch outside the measured disagreement band around the compare
               (CE_Predictive_Node.cpp:245-261 `>= 0.8`; the threshold plans' `feature > thr`): the GPU forms its fp32 features in

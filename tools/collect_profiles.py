@@ -3,14 +3,14 @@
 profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(R, "gpurun_out", tag)
 DST = os.path.join(R, "profiles")
 os.makedirs(DST, exist_ok=True)
 for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("bench_headline.json", f"{tag}_bench_headline.json"),
                  ("bench_cfg1_1024.json", f"{tag}_bench_cfg1_1024pt.json"), ("bench_cfg3_ref512.json", f"{tag}_bench_cfg3_ref512.json"),
                  ("bench_cfg2_welch.json", f"{tag}_bench_cfg2_welch.json"), ("host_rate.txt", f"{tag}_host_buffer_rate.txt"),
-                 ("bench_unpruned.json", f"{tag}_bench_headline_unpruned.json"), ("bench_noclose.json", f"{tag}_bench_ablation_no_epoch_close.json"),
+                 ("bench_unpruned.json", f"{tag}_bench_headline_unpruned.json"),
                  ("bench_e512.json", f"{tag}_bench_energy_512pt.json"), ("bench_e2048.json", f"{tag}_bench_energy_2048pt.json"),
                  ("membw_policy.txt", f"{tag}_stream_ceiling_policy.txt"), ("cfg3_decisions.txt", f"{tag}_cfg3_decisions_1M_epochs.txt"),
                  ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("smoke.log", f"{tag}_smoke.log"),
@@ -19,9 +19,11 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("power_probe.txt", f"{tag}_power_clock_probe.txt"), ("cpu_scaling.txt", f"{tag}_cpu_thread_scaling.txt"),
                  ("per_bin_error_at_floor.txt", f"{tag}_per_bin_error_at_floor.txt"),
                  ("engine_execute_latency.txt", f"{tag}_engine_execute_latency.txt"),
-                 ("bench_adc16.jsonl", f"{tag}_bench_radio_format_input.jsonl"),
-                 ("bench_wire_format.jsonl", f"{tag}_bench_wire_format_sc16.jsonl"), ("ring_rate.txt", f"{tag}_ring_rate_round.txt"),
-                 ("bench_v23.json", f"{tag}_bench_headline_all_twiddles_in_registers.json"),
+                 ("ring_rate.txt", f"{tag}_ring_rate_round.txt"),
+                 ("bench_strong_share_per_gpu.jsonl", f"{tag}_bench_strong_share_per_gpu.jsonl"),
+                 ("bench_strong_share_per_gpu_one_stream.jsonl", f"{tag}_bench_strong_share_per_gpu_one_stream.jsonl"),
+                 ("bench_8ranks_one_gpu_strong.json", f"{tag}_bench_eight_self_launched_ranks_one_gpu_stand_in_wire_strong.json"),
+                 ("decision_band.txt", f"{tag}_decision_band.txt"),
                  ("bench_driver_shape.json", f"{tag}_bench_driver_shape.json"),
                  ("bench_8ranks_one_gpu.json", f"{tag}_bench_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
                  ("bench_8ranks_one_gpu_scan.json", f"{tag}_bench_cfg4_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
@@ -47,7 +49,7 @@ def mean_counter(sub, name):
 HOW = ("rocprofv3 --pmc FETCH_SIZE [GRBM_GUI_ACTIVE] and --pmc WRITE_SIZE [TCC_HIT_sum TCC_MISS_sum] in separate passes "
        "(--kernel-trace only) over `python3 bench.py --steps 5 --warmup 20 --cpu-epochs 0 <workload flags>`; FETCH_SIZE is KiB and on "
        "gfx950 tallies each 128-B request as 64 B, so x2 (MI355X_MICROARCH.md, HBM section); the x2 was re-calibrated for "
-       "this kernel's 8-B-per-lane loads with tools/membw (profiles/r01_fetch_size_calibration.txt (round 1; the load instruction is unchanged))")
+       "this kernel's 8-B-per-lane loads in round 1 (docs/history: the load instruction is unchanged since)")
 out = {"_how": HOW}
 # key = bench.py's f"{mode}{N}"; the unpruned 4096-pt kernel is recorded for the record only
 for key, sub, bench in (("energy4096", "_headline", "bench_headline.json"), ("energy1024", "_cfg1", "bench_cfg1_1024.json"),

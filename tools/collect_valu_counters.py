@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_valu_counters.json from the SQ / GRBM counter passes of tools/gpu_pmc.sh (gpurun_out/pmc_<name>):
+"""profiles/valu_counters.json from the SQ / GRBM counter passes of tools/gpu_pmc.sh (gpurun_out/pmc_<name>):
 per workload the measured clock (GRBM_GUI_ACTIVE / 8 XCDs / kernel time), the VALU-busy fraction at that clock
 (SQ_ACTIVE_INST_VALU is in quad-cycles: x 4 / (1024 SIMDs x kernel cycles)), VALU instructions per wave per frame,
 and the LDS-wait share of wave cycles.  bench.py prints these beside the VALU roofline of the windowed modes.
@@ -58,7 +58,7 @@ for spec in sys.argv[2:]:
         "raw": {k: c[k] for k in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS",
                                   "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_DATA_FIFO_FULL",
                                   "SQ_VMEM_TA_ADDR_FIFO_FULL", "SQ_BUSY_CYCLES", "FETCH_SIZE") if k in c},
-        "source": f"profiles/{tag}_valu_counters.json <- gpurun_out/{sub} (rocprofv3 --pmc, tools/gpu_pmc.sh)",
+        "source": f"profiles/valu_counters.json (round {tag}) <- gpurun_out/{sub} (rocprofv3 --pmc, tools/gpu_pmc.sh)",
     }
     print(key, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out[key].items() if k != "raw"})
-json.dump(out, open(os.path.join(R, "profiles", f"{tag}_valu_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "profiles", "valu_counters.json"), "w"), indent=1)

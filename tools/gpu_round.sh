@@ -1,12 +1,14 @@
 #!/bin/bash
-# Round evidence (tag $TAG, default r03): GPU tests, smoke, every bench line, rocprofv3 kernel stats of the headline
-# command, HBM traffic counters (separate --pmc passes per workload), SQ / GRBM counter groups for the VALU-side
-# figures, the engine's execute() latency, host-buffer (PCIe-inclusive) rate, zero-input and power / clock probes.
+# Round evidence (tag $TAG, default r04), one gpurun call, one box: GPU tests, smoke, every bench line (single GPU; N = 8 rehearsed in
+# both scaling modes over the stand-in RCCL), rocprofv3 kernel stats of the headline command, HBM traffic counters (separate --pmc
+# passes per workload), SQ / GRBM counter groups, the engine's execute() latency, host-buffer (PCIe-inclusive) rate, probes.
+#   gpurun --timeout 3600 -- 'bash tools/gpu_round.sh'   then   python tools/collect_profiles.py r04
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+[ -x tools/membw_policy ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/membw_policy tools/membw_policy.hip
 CRN_EVIDENCE_DIR=$O timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 timeout 600 python bench.py > $O/bench_headline.json 2> $O/bench_headline.err
@@ -15,23 +17,24 @@ timeout 300 python bench.py --mode ref --cpu-epochs 0 > $O/bench_cfg3_ref512.jso
 timeout 300 python bench.py --mode welch --cpu-epochs 0 > $O/bench_cfg2_welch.json 2> $O/bench_cfg2.err
 timeout 300 python bench.py --mode welch --cpu-epochs 0 --frames 32 > $O/bench_cfg2_welch_K32.json 2> $O/bench_cfg2_K32.err
 timeout 300 python bench.py --mode scan --cpu-epochs 0 --force-collective > $O/bench_cfg4_scan_1rank.json 2> $O/bench_cfg4.err
-timeout 300 python bench.py --variant 16 --cpu-epochs 0 --no-check --no-alt > $O/bench_noclose.json 2> $O/bench_noclose.err   # (A/B build: libcrnsense_ab.so)
 timeout 300 python bench.py --variant 2 --cpu-epochs 0 --no-alt > $O/bench_unpruned.json 2> $O/bench_unpruned.err
-timeout 300 python bench.py --variant 23 --cpu-epochs 0 --no-alt > $O/bench_v23.json 2> $O/bench_v23.err
-# the driver's command shape, and BASELINE.json configs[4] rehearsed the way the driver starts it: no launcher, bench.py starts its own
-# ranks; eight of them share this box's one GPU over the stand-in RCCL (real RCCL refuses two ranks per device)
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
-CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0 timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --epochs 3584 --cpu-epochs 0 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err
-CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0 timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --mode scan --epochs 8960 --cpu-epochs 0 > $O/bench_8ranks_one_gpu_scan.json 2> $O/bench_8ranks_one_gpu_scan.err
-timeout 900 python tools/gpu_welch_spans.py > $O/welch_spans.txt 2>&1
-timeout 900 python tests/soak_gpu.py 20000 > $O/soak.txt 2>&1
 timeout 300 python bench.py --fft 512 --cpu-epochs 0 > $O/bench_e512.json 2> $O/bench_e512.err
 timeout 300 python bench.py --fft 2048 --cpu-epochs 0 > $O/bench_e2048.json 2> $O/bench_e2048.err
-# the same kernels on samples rounded to the USRP's 16-bit wire format (what the reference's radios deliver): diagnostic lines
-{ for m in "--mode welch" "--mode ref" "--fft 1024" "--fft 2048"; do timeout 300 python bench.py $m --adc-bits 16 --cpu-epochs 0 --no-live-traffic --no-alt 2>/dev/null | tail -1; done; } > $O/bench_adc16.jsonl
-{ for m in "" "--fft 1024" "--fft 512" "--fft 2048" "--mode ref" "--mode welch"; do timeout 300 python bench.py $m --wire-format --cpu-epochs 0 2>/dev/null | tail -1; done; } > $O/bench_wire_format.jsonl
+# the driver's command shape; the N = 1 end of the strong-scaling curve and its per-GPU shares at N = 2 / 4 / 8 as ONE-GPU launches
+# (what one rank of the strong-scaled job runs: 1/N of the 8.75 GiB batch, two streams below 4 GiB) — the kernel-side scaling loss
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
+{ for n in 1 2 4 8; do timeout 300 python bench.py --steps 40 --warmup 10 --cpu-epochs 0 --no-alt --no-live-traffic --epochs $((28672 / n)) $([ $n -gt 2 ] && echo --two-streams) 2>/dev/null | tail -1; done; } > $O/bench_strong_share_per_gpu.jsonl
+{ for n in 4 8; do timeout 300 python bench.py --steps 40 --warmup 10 --cpu-epochs 0 --no-alt --no-live-traffic --epochs $((28672 / n)) 2>/dev/null | tail -1; done; } > $O/bench_strong_share_per_gpu_one_stream.jsonl
+# BASELINE.json configs[4] rehearsed the way the driver starts it (no launcher: bench.py starts its own ranks), eight ranks sharing this
+# box's one GPU over the stand-in RCCL (real RCCL refuses two ranks per device), weak and strong scaling
+export CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --epochs 3584 --cpu-epochs 0 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --scaling strong --cpu-epochs 0 > $O/bench_8ranks_one_gpu_strong.json 2> $O/bench_8ranks_one_gpu_strong.err
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --mode scan --epochs 8960 --cpu-epochs 0 > $O/bench_8ranks_one_gpu_scan.json 2> $O/bench_8ranks_one_gpu_scan.err
+unset CRN_RCCL_LIB HIP_VISIBLE_DEVICES
+timeout 900 python tools/gpu_welch_spans.py > $O/welch_spans.txt 2>&1
+timeout 900 python tests/soak_gpu.py 20000 > $O/soak.txt 2>&1
 timeout 120 tools/ring_rate 64 256 3 > $O/ring_rate.txt 2>&1; timeout 60 tools/ring_rate 1 1 3 >> $O/ring_rate.txt 2>&1
-timeout 120 tools/ring_rate 64 256 3 sc16 >> $O/ring_rate.txt 2>&1
 ./tools/membw_policy > $O/membw_policy.txt 2>&1
 timeout 300 python tools/host_rate.py > $O/host_rate.txt 2>&1
 timeout 300 python tools/engine_rate.py > $O/engine_rate.txt 2>&1
@@ -53,4 +56,4 @@ for cfgname in "headline:" "welch:--mode welch" "e2048:--fft 2048" "ref:--mode r
   tag=${cfgname%%:*}; args=${cfgname#*:}
   TAG=${TAG}_$tag EXTRA="--no-alt $args" bash tools/gpu_pmc.sh > $O/pmc_sq_$tag.txt 2>&1
 done
-tail -3 $O/pytest_gpu.log; tail -3 $O/smoke.log; cat $O/bench_headline.json; cat $O/engine_rate.txt
+tail -3 $O/pytest_gpu.log; tail -3 $O/smoke.log; cat $O/bench_headline.json; cat $O/bench_strong_share_per_gpu.jsonl | cut -c1-400; cat $O/engine_rate.txt
