@@ -64,7 +64,8 @@ def test_live_updates_against_the_ring_launcher_thread(built):
     """tests/harness/api_race_unit.cpp: one thread pushes packets through a real ingest ring (whose launcher thread launches through
     the handle) while another swaps the band plan (same number of bands) and the thresholds in a loop — crn_api.cpp + crn_ingest.cpp
     as they are over the host-only HIP stand-in.  Every launch must see one plan, whole; crn_sense_destroy is refused while the ring is
-    attached.  ThreadSanitizer build, then AddressSanitizer + UBSan (a launch that kept a pointer into a freed table slab is a report)."""
+    attached.  ThreadSanitizer build, then AddressSanitizer + UBSan (a launch that kept a pointer into a freed table slab is a report).
+    (Sensitivity, checked by hand in round 4: with the lock taken out of run_device_impl the same program draws 25 ThreadSanitizer reports.)"""
     for name in ("api_race_unit", "api_race_unit_asan"):
         exe = os.path.join(HARNESS, name)
         subprocess.check_call(["make", "-C", HARNESS, exe], stdout=subprocess.DEVNULL)
