@@ -92,3 +92,19 @@ def test_occupancy_exchange_as_a_world_of_two_ranks(built):
     receives [rank 0 block][rank 1 block], slots alternate and are reused, argument errors are refused.  The hardware run at N > 1
     is the driver's; this is the same code path with everything but the wire."""
     _run_unit("comm_unit", 3, os.path.join(HARNESS, "libfake_rccl.so"))
+
+
+def test_parity_policy_is_one_consistent_definition():
+    """tests/parity_policy.py is what smoke(), the GPU tests and DESIGN.md §2 quote: the per-bin bound is 1e-5 up to +30 dB and
+    continuous in SNR above it up to the fitted line's headroom, the fixtures' default traffic sits at +38.3 dB, and the decision
+    margins are exactly 10 x the measured disagreement bands."""
+    import math
+    import parity_policy as pol
+    for n in (512, 1024, 2048, 4096):
+        assert pol.snr_bound(n, None) == pol.snr_bound(n, 0) == pol.snr_bound(n, 30) == pol.PER_BIN_TOL == 1e-5
+        assert pol.snr_bound(n, 30.01) < 1.51e-5 and pol.snr_bound(n, 36) < 3.0e-5 and pol.snr_bound(n, 40) > pol.snr_bound(n, 36)
+    snr = pol.in_band_snr_db(0.02, 1e-6, 30, 512)          # a channel of 30 of 512 bins driven at rms 0.02 over noise power 1e-6
+    assert abs(snr - pol.DEFAULT_TRAFFIC_SNR_DB) < 0.05 and pol.in_band_snr_db(0.0, 1e-6, 30, 512) is None
+    assert math.isclose(pol.snr_bound(4096, snr), 1.5e-5 * 10 ** ((snr - 30) / 20))
+    assert pol.ANN_MARGIN == 10 * pol.ANN_DISAGREEMENT_BAND and pol.THRESHOLD_MARGIN == 10 * pol.THRESHOLD_DISAGREEMENT_BAND
+    assert pol.ANN_MARGIN < 1e-5 and pol.THRESHOLD_MARGIN < 1e-5     # measured, not the 1e-3 / 1e-4 of earlier rounds
