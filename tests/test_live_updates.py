@@ -200,3 +200,105 @@ def test_noise_floor_from_host_features(built):
     check = cs.lib().crn_sense_synchronize(s._h, None)
     assert check == 0
     s.close()
+
+
+@pytest.mark.gpu
+def test_band_plan_swaps_against_a_running_ring_on_the_gpu(built):
+    """The hardware counterpart of tests/harness/api_race_unit.cpp: one thread pushes packets through an ingest ring (its launcher
+    thread launches through the handle) while another swaps the band plan between two plans — same number of bands — and the
+    thresholds, 300 times.  Every epoch carries one tone; under plan A its bin lies in band 1, under plan B in band 2: each result
+    must be exactly plan A's or plan B's answer (the tone's energy in ONE of the two bands, the other at noise level), never a
+    mix, never an error from the launcher thread — and the handle cannot be destroyed while the ring is attached."""
+    import threading
+    n, K, L = 1024, 10, 1024
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    plan_a = [(600, 620, 0), (8, 24, 1), (110, 170, 2), (378, 444, 3)]
+    plan_b = [(600, 620, 0), (40, 72, 1), (8, 24, 2), (378, 444, 3)]
+    thr = [cfg.thresh[b] for b in range(4)]
+    s = cs.Sensor(cfg)
+    s.set_bands(plan_a, 4, thr)
+    ring = cs.Ingest(s, 2, L, 4)
+    with pytest.raises(cs.CrnError, match="ingest ring"):
+        cs.check(cs.lib().crn_sense_destroy(s._h), "crn_sense_destroy")
+    rng = np.random.default_rng(77)
+    t = np.arange(L)
+    pkt = (rng.normal(0, 7e-4, L) + 1j * rng.normal(0, 7e-4, L) + 0.02 * np.exp(2j * np.pi * 16 * t / n)).astype(np.complex64).view(np.float32).copy()
+    stop, results, errors = threading.Event(), [], []
+
+    def pusher():
+        try:
+            while not stop.is_set():
+                for st in range(2):
+                    ring.push(st, pkt, block=True)
+                results.extend((r.features[1], r.features[2]) for r in ring.poll(64))
+        except Exception as e:   # noqa: BLE001 — reported by the main thread
+            errors.append(e)
+    th = threading.Thread(target=pusher)
+    th.start()
+    try:
+        for it in range(300):
+            s.set_bands(plan_b if it & 1 else plan_a, 4, None)
+            s.set_thresholds([t0 * (1.0 + 1e-3 * (it % 7)) for t0 in thr])
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    ring.drain()
+    results.extend((r.features[1], r.features[2]) for r in ring.poll(4096))
+    ring.close()
+    s.close()
+    f = np.array(results, np.float64)
+    assert len(f) > 50
+    tone = (0.02 * n) ** 2                      # |X|^2 of the tone's bin, K-frame mean
+    in1 = np.abs(f[:, 0] / tone - 1) < 0.05     # plan A: the tone (bin 16) lies in band 1 = [8, 24)
+    in2 = np.abs(f[:, 1] / tone - 1) < 0.05     # plan B: in band 2 = [8, 24)
+    assert (in1 ^ in2).all(), "an epoch saw a mix of the two plans (or neither)"
+    assert in1.any() and in2.any()
+    assert (np.where(in1, f[:, 1], f[:, 0]) < 1e-3 * tone).all()      # the other band holds noise only
+
+
+@pytest.mark.gpu
+def test_ring_calibration_and_one_call_calibration_on_the_gpu(built):
+    """crn_ingest_calibrate on hardware: the ring's launcher thread measures the noise floor over the first epochs that come back and
+    sets the thresholds; marked epochs first, then unmarked ones carrying the estimate — which equals crn_noise_floor_host's on the
+    same features and crn_sense_calibrate_thresholds' (the synchronous engine's one allocation-free call), and the thresholds in force
+    afterwards are lambda x it (a tone far above them reads occupied, noise bands idle)."""
+    n, K = 1024, 8
+    cfg = cs.cfg_welch(n, K, 64)
+    for b in range(64):
+        cfg.thresh[b] = float("inf")
+    s = cs.Sensor(cfg)
+    ring = cs.Ingest(s, 1, n, 1)
+    ring.calibrate(6, 4.0)
+    with pytest.raises(cs.CrnError):
+        ring.calibrate(6, 4.0)                   # one at a time
+    P = ring.packets_per_epoch()
+    rng = np.random.default_rng(5)
+    t = np.arange(n)
+    got = []
+    for e in range(14):
+        for p in range(P):
+            x = rng.normal(0, 7e-4, n) + 1j * rng.normal(0, 7e-4, n)
+            if e >= 8:
+                x = x + 0.02 * np.exp(2j * np.pi * 200 * (t + p * n) / n)     # band 200 // 16 = 12 driven in the later epochs
+            ring.push(0, x.astype(np.complex64).view(np.float32).copy())
+        ring.drain()                             # one epoch at a time: exactly six epochs feed the estimate
+        got.extend(ring.poll(8))
+    ring_nf, busy = ring.noise_floor()
+    ring.close()
+    assert len(got) == 14 and not busy
+    flags = [r.flags & cs.EPOCH_CALIBRATION for r in got]
+    assert flags == [1] * 6 + [0] * 8
+    feats = np.array([list(r.features[:64]) for r in got], np.float32)
+    nf_host = s.noise_floor_host(feats[:6])
+    assert ring_nf == nf_host and all(r.noise_floor == nf_host for r in got[6:]) and all(r.noise_floor == 0 for r in got[:6])
+    occ = np.array([list(r.occupancy[:64]) for r in got])
+    assert not occ[:8].any()                                   # calibration epochs (+inf thresholds) and idle epochs: nothing occupied
+    assert occ[8:, 12].all() and occ[8:].sum() == 6            # the driven band, and only it, against 4 x the measured floor
+    s2 = cs.Sensor(cs.cfg_welch(n, K, 64))
+    with pytest.raises(cs.CrnError, match="reserve"):
+        s2.calibrate_thresholds(feats[:6], 4.0)                # allocates nothing: the buffers must have been reserved
+    s2.reserve_noise_floor()
+    assert s2.calibrate_thresholds(feats[:6], 4.0) == nf_host and s2.cfg.thresh[0] == np.float32(4.0) * np.float32(nf_host)
+    s2.close()
+    s.close()
