@@ -50,6 +50,14 @@ CE_Predictive_Node_GPU::CE_Predictive_Node_GPU(int argc, char **argv, Extensible
   memset(ch_bands, 0, sizeof(ch_bands));
   memset(recent_decisions, 0, sizeof(recent_decisions));
 
+  // the library this process loaded must speak the ABI this file was compiled against (struct layouts: crn_cfg, crn_epoch_result);
+  // crn_cfg.abi_version cannot tell — the crn_cfg_* helpers below fill it in with the LIBRARY's version
+  if (crn_abi_version() != CRN_ABI_VERSION) {
+    fprintf(stderr, "CE_Predictive_Node_GPU: libcrnsense speaks ABI version %d, this engine was built against %d (rebuild one of them)\n",
+            crn_abi_version(), CRN_ABI_VERSION);
+    exit(EXIT_FAILURE);
+  }
+
   // ce_args from the scenario file arrive as argv (reference: src/crts.cpp:43-81 str2argcargv,
   // which resets optind; CE_Template.cpp:17-25 shows the getopt idiom)
   int o;

@@ -38,6 +38,8 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   g_created_cfg = *cfg;
   return CRN_OK;
 }
+static int g_fake_abi_version = CRN_ABI_VERSION;
+int crn_abi_version(void) { return g_fake_abi_version; }
 int crn_sense_destroy(crn_handle *h) { delete h; return CRN_OK; }
 int crn_sense_reserve_host(crn_handle *, int64_t, int32_t) { return CRN_OK; }
 static int g_timing_requests = 0;
@@ -416,6 +418,16 @@ int main() {
     e->release();
     delete e;
     g_fake_gpu_latency_ns = 0;
+  }
+  // ---- a library of another ABI version ends the run at construction (struct layouts differ: nothing may be called) -----------------
+  {
+    g_fake_abi_version = CRN_ABI_VERSION - 1;
+    const int st = exit_status_of([] {
+      ECRd ecr;
+      make_engine(ecr, {"-g", "0", "-v", "0"});
+    });
+    g_fake_abi_version = CRN_ABI_VERSION;
+    REQUIRE(st == EXIT_FAILURE);
   }
   // ---- -w: the trainer's weights reach the engine through a file, at another FFT size ----------------------------------------------
   {
