@@ -132,6 +132,8 @@ def lib():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
+        if L.crn_abi_version() != CRN_ABI_VERSION:   # the ctypes structures below mirror ONE version of include/crn_sense.h
+            raise CrnError(f"{LIB_PATH} speaks ABI version {L.crn_abi_version()}, crnsense.py mirrors version {CRN_ABI_VERSION}: rebuild the library")
         L.crn_last_error.restype = C.c_char_p
         L.crn_build_info.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.crn_cfg_reference.argtypes = [C.POINTER(Cfg)]
