@@ -164,6 +164,15 @@ int main(int argc, char **argv) {
   if (!all_ranks_ready(id_file, rank, world, setup_rc == 0)) return 1;
   crn_comm *comm = NULL;
   CHECK(crn_comm_create(device, rank, world, id, E * 64, 2, &comm));
+  {  // what RCCL itself says the communicator is: it must be this job's `world` ranks, and this rank's place in it
+    crn_comm_info_t ci;
+    CHECK(crn_comm_info(comm, &ci));
+    if (ci.nranks != world || ci.rank != rank) {
+      fprintf(stderr, "scan_node: rank %d/%d: RCCL reports a communicator of %d ranks, this one rank %d\n", rank, world, ci.nranks, ci.rank);
+      return 1;
+    }
+    if (rank == 0) printf("scan_node: RCCL communicator: %d ranks, rank 0 on device %d, version %d, library %s\n", ci.nranks, ci.rccl_device, ci.rccl_version, ci.library);
+  }
 
   auto step = [&](int64_t i) -> int {
     uint8_t *occ = NULL;

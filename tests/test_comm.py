@@ -58,6 +58,9 @@ def test_one_rank_communicator_end_to_end(built):
         assert np.array_equal(got, want), step
         assert np.array_equal(dec.cpu().numpy(), picks)
     assert len(ptrs) == 2
+    info = comm.info()                         # asked of RCCL (ncclCommCount / UserRank / CuDevice / GetVersion), not echoed
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["rccl_device"] == 0 and info["rccl_version"] >= 20000
+    assert info["gathers"] == 5 and info["depth"] == 2 and info["bytes_per_rank"] == E * cfg.n_bands and "rccl" in info["library"]
     with pytest.raises(cs.CrnError):
         comm.local(-1, stream)
     sensor.close()
@@ -95,6 +98,8 @@ def test_scan_node_cpp_program_over_the_c_abi(built, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank 0/1")][0]
     assert "own block in place: yes" in line and "driven channel flagged in 1024 of 1024 epochs" in line
+    comm_line = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node: RCCL communicator:")][0]
+    assert "1 ranks, rank 0 on device 0" in comm_line and "version 2" in comm_line      # real RCCL 2.x, asked of the communicator itself
     occupied = float(line.split(" epochs, ")[-1].split()[0])
     assert 1.0 <= occupied < 8.0       # the driven channel, plus splatter where the traffic changes inside a frame
     print(line)
@@ -112,6 +117,7 @@ def test_scan_node_two_processes_on_one_gpu(built):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("scan_node rank")]
     assert len(lines) == 2 and any("rank 0/2" in ln for ln in lines) and any("rank 1/2" in ln for ln in lines), out.stdout
+    assert "scan_node: RCCL communicator: 2 ranks" in out.stdout
 
 
 @pytest.mark.gpu
