@@ -9,6 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 [ -x tools/membw_policy ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/membw_policy tools/membw_policy.hip
+[ -x tools/ring_rate ] || make -C tests/harness ring_rate > /dev/null
 CRN_EVIDENCE_DIR=$O timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 timeout 600 python bench.py > $O/bench_headline.json 2> $O/bench_headline.err
