@@ -108,3 +108,39 @@ def test_parity_policy_is_one_consistent_definition():
     assert math.isclose(pol.snr_bound(4096, snr), 1.5e-5 * 10 ** ((snr - 30) / 20))
     assert pol.ANN_MARGIN == 10 * pol.ANN_DISAGREEMENT_BAND and pol.THRESHOLD_MARGIN == 10 * pol.THRESHOLD_DISAGREEMENT_BAND
     assert pol.ANN_MARGIN < 1e-5 and pol.THRESHOLD_MARGIN < 1e-5     # measured, not the 1e-3 / 1e-4 of earlier rounds
+
+
+def test_asm_wait_state_filter(tmp_path):
+    """csrc/strip_asm_nops.py (run by csrc/hipcc_kernels.sh on the gfx950 assembly of the kernel files): drops `s_nop 0` only between two
+    inline-asm statements of packed-f32 instructions (or after one of the LDS read blocks that end with their own wait); every s_nop
+    with a compiler-generated neighbour, every longer s_nop, and statements holding anything else are left exactly as they were."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(HARNESS), "..", "cognitive-radio-network_amd", "csrc", "strip_asm_nops.py")
+    spec = importlib.util.spec_from_file_location("strip_asm_nops", os.path.abspath(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def asm(*body):
+        return ["\t;;#ASMSTART"] + ["\t" + b for b in body] + ["\t;;#ASMEND"]
+    pk_a = asm("v_pk_add_f32 v[0:1], v[2:3], v[4:5]")
+    pk_b = asm("v_pk_fma_f32 v[6:7], v[0:1], s[2:3], v[8:9] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]")
+    pk_c = asm("v_pk_mul_f32 v[10:11], v[6:7], v[12:13] op_sel_hi:[1,0]")
+    lds = asm("ds_read_b64 v[20:21], v30 offset:0", "ds_read_b64 v[22:23], v30 offset:128", "s_waitcnt lgkmcnt(0)")
+    other = asm("v_mov_b32 v40, v41")
+    src = (pk_a + ["\ts_nop 0"] + pk_b                        # 1: dropped
+           + ["\t; a comment the compiler left", "\ts_nop 0"] + pk_c   # 2: dropped (comments do not count)
+           + ["\ts_nop 0", "\tv_fmac_f32_e32 v50, v10, v10"]           # kept: the consumer is the compiler's
+           + pk_a + ["\ts_nop 1"] + pk_b                               # kept: a longer wait is somebody's real hazard
+           + lds + ["\ts_nop 0"] + pk_c                                # 3: dropped (the block closed with its own wait)
+           + other + ["\ts_nop 0"] + pk_a                              # kept: not a packed-f32 statement
+           + pk_b + ["\tv_readlane_b32 s5, v6, 16", "\ts_nop 0"] + pk_c   # kept: a compiler instruction came between
+           + ["\ts_add_i32 s3, s2, 0x800", "\ts_nop 0", "\ts_endpgm"])   # kept: nothing to do with inline asm
+    fin, fout = tmp_path / "in.s", tmp_path / "out.s"
+    fin.write_text("\n".join(src))
+    mod.main(str(fin), str(fout))
+    out = fout.read_text().split("\n")
+    assert len(out) == len(src) - 3 and out.count("\ts_nop 0") == src.count("\ts_nop 0") - 3 and out.count("\ts_nop 1") == 1
+    assert [ln for ln in out if "s_nop" not in ln] == [ln for ln in src if "s_nop" not in ln]     # nothing else was touched
+    kept_after = [out[i + 1].strip() for i, ln in enumerate(out) if ln.strip() == "s_nop 0"]
+    assert kept_after == ["v_fmac_f32_e32 v50, v10, v10", ";;#ASMSTART", ";;#ASMSTART", "s_endpgm"]
