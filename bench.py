@@ -222,6 +222,9 @@ def main():
     # RCCL prints a version banner at init) writes to fd 1 goes to stderr instead.
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    # ranks started by a launcher that did not export it: RCCL between processes needs dmabuf IPC on this driver, and the HSA
+    # runtime reads the variable when the first HIP call initialises it (nothing has touched the GPU yet)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch

@@ -31,7 +31,7 @@ EXPORTS = [
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
     "crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
-    "crn_sense_kernel_info", "crn_sense_set_variant",
+    "crn_sense_kernel_info", "crn_sense_set_variant", "crn_sense_dealt_launches",
     "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped", "crn_ingest_packets_per_epoch",
     "crn_noise_floor_device", "crn_sense_set_thresholds", "crn_sense_reserve_noise_floor", "crn_sense_calibrate_thresholds",
@@ -188,6 +188,7 @@ def lib():
         L.crn_ingest_calibrate.argtypes = [C.c_void_p, C.c_int32, C.c_float]
         L.crn_ingest_noise_floor.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.crn_sense_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.crn_sense_dealt_launches.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.crn_sense_get_stats.argtypes = [C.c_void_p, C.POINTER(SenseStats)]
         L.crn_ingest_get_stats.argtypes = [C.c_void_p, C.POINTER(IngestStats)]
         L.crn_monitor_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32,
@@ -362,6 +363,12 @@ class Sensor:
         st = SenseStats()
         check(lib().crn_sense_get_stats(self._h, C.byref(st)), "crn_sense_get_stats")
         return {k: getattr(st, k) for k, _ in SenseStats._fields_}
+
+    def dealt_launches(self):
+        """Launches of this handle that ran the dealt-frame form of the kernel (small launches at 512 / 1024 points)."""
+        n = C.c_int64()
+        check(lib().crn_sense_dealt_launches(self._h, C.byref(n)), "crn_sense_dealt_launches")
+        return n.value
 
     def kernel_info(self):
         name = C.create_string_buffer(256)

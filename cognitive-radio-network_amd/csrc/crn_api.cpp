@@ -35,6 +35,8 @@ struct crn_handle {
   int groups_per_wg = 0;        // 0 = automatic
   int64_t tail_groups = -1;     // < 0 = automatic; epoch groups handed to the short tail workgroups at the end
   int tail_groups_per_wg = 0;   // 0 = automatic; epoch groups per tail workgroup
+  std::atomic<int64_t> n_dealt{0};   // launches that ran the dealt-frame kernel (crn_sense_dealt_launches)
+  int64_t deal_max_epochs = -1; // launches of up to this many epochs run the dealt-frame kernel where it exists (< 0: automatic, from n_cus)
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   std::atomic<int> n_rings{0};  // ingest rings created on this handle (they size their result buffers for cfg.n_bands)
@@ -385,6 +387,12 @@ int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) {
   return CRN_OK;
 }
 
+int crn_sense_dealt_launches(crn_handle *h, int64_t *n) {
+  if (!h || !n) return crn::fail(CRN_ERR_ARG, "null handle / counter");
+  *n = h->n_dealt.load(std::memory_order_relaxed);
+  return CRN_OK;
+}
+
 int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->tables_mu);
@@ -398,6 +406,10 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   }
   if (variant >= 300 && variant <= 364) {  // A/B: 300 + n = n epoch groups per tail workgroup (300 = automatic)
     h->tail_groups_per_wg = variant - 300;
+    return CRN_OK;
+  }
+  if (variant >= 400 && variant <= 402) {  // A/B: the dealt-frame kernel of small launches: 400 automatic, 401 never, 402 at any batch size
+    h->deal_max_epochs = variant == 400 ? -1 : variant == 401 ? 0 : (int64_t)0x7fffffff;
     return CRN_OK;
   }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
@@ -575,6 +587,17 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     p.tail_groups_per_wg = (int)(h->tail_groups_per_wg > 0 ? h->tail_groups_per_wg : tail_epw);
     p.n_big_wgs = (n_groups - tail) / p.groups_per_wg;
   }
+  {
+    // A launch of a few epochs (the engine's: one) leaves most of every workgroup idle in the streaming kernel — an epoch is one lane
+    // group running its K frames one after the other.  Up to one epoch per compute unit the dealt-frame kernel spreads an epoch's
+    // frames over the lane groups of a workgroup of its own instead (csrc/crn_sense_kernel.h: sense_kernel_dealt; same results bit
+    // for bit).  Measured (profiles/r04_dealt_frames_ab.txt, us per launch, streaming -> dealt): 1 reference epoch 19.7 -> 10.0 from
+    // HBM and 29.4 -> 15.4 from pinned host memory (the ring's launch); 256 epochs 20.3 -> 10.9; from 512 epochs on — two
+    // workgroups per CU — the energy forms lose (17.5 -> 20.5), so the switch sits at one per CU.
+    const int64_t deal_max = h->deal_max_epochs >= 0 ? h->deal_max_epochs : (int64_t)h->n_cus;
+    if (n_epochs <= deal_max && c.window == CRN_WINDOW_RECT && (h->variant == 0 || h->variant == 13))
+      p.deal_rounds = crn::sense_deal_rounds(c.fft_len, c.mode == CRN_MODE_REF_MAG, c.frames_per_epoch);
+  }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;
   p.window = h->d_window;
@@ -622,6 +645,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
   const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
   h->n_launches.fetch_add(1, std::memory_order_relaxed);
+  if (p.deal_rounds > 0) h->n_dealt.fetch_add(1, std::memory_order_relaxed);
   h->n_epochs.fetch_add(n_epochs, std::memory_order_relaxed);
   h->n_samples.fetch_add((n_epochs - 1) * std::min(epoch_stride, extent) + extent, std::memory_order_relaxed);
   return CRN_OK;

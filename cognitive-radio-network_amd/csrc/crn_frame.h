@@ -140,6 +140,8 @@ enum : int {
                     // acc_mask, the 256-bin rows no band touches — kRows' pruning decided at run time.  Measured SLOWER than forming
                     // every row (80.3 vs 82.4 % on the reference plan, 77.0 vs 81.0 % on a dense one): a dozen scalar branches
                     // per frame cost an in-order wave more than the 9 x 3 instructions they skip; not shipped
+  kDeal = 1048576,  // sense_kernel_dealt (launches of a few epochs): one epoch per workgroup, its frames dealt to the lane groups; pass 3
+                    // parks each frame's per-bin values in LDS (ph_pass3_park) and the accumulate is replayed in frame order afterwards
 };
 
 template <int R3_, int NBUF_, bool PREFETCH_, bool NT_, bool MAG_, bool WIN_, bool TW2LDS_, int OCC_, int ABL_,
@@ -177,6 +179,7 @@ struct FrameCtx {
   cx *gbuf;     // this group's exchange buffers
   int t, a, m_lo, L;
   unsigned rt_mask;   // kRowsRT: the launch's acc_mask (wave-uniform)
+  unsigned park_off;  // kDeal: LDS byte offset of the slot the current frame's per-bin values go to
   float Kf, invK;
 };
 
@@ -531,9 +534,54 @@ CRN_DEV void ph_pass3_acc_rt(cx (&u)[16], FrameCtx<C> &c) {
 
 #endif  // CRN_AB_VARIANTS
 
+// kDeal: pass 3, then the frame's per-bin values — |X| (MAG) or X itself (energy mode: the accumulate is a chain of two fmas on the
+// parts) — go to the frame's LDS slot, [16 registers][T threads], instead of into the accumulators: the workgroup's lane groups
+// work on different frames of ONE epoch, and the K-frame accumulate is replayed from the slots in frame order (replay_parked), so
+// the sums are bit for bit the streaming kernel's.
+typedef __attribute__((address_space(3))) float lds_park_f32;
+typedef __attribute__((address_space(3))) cx lds_park_cx;
+template <class C>
+CRN_DEV void ph_pass3_park(cx (&u)[16], FrameCtx<C> &c) {
+  constexpr int T = Geo<C::R3>::T;
+  cx v[16];
+  ph_pass3<C>(u, v);
+  if constexpr (C::MAG) {
+    lds_park_f32 *slot = reinterpret_cast<lds_park_f32 *>(c.park_off);
+#pragma unroll
+    for (int i = 0; i < 16; i++) slot[i * T + c.t] = __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+  } else {
+    lds_park_cx *slot = reinterpret_cast<lds_park_cx *>(c.park_off);
+#pragma unroll
+    for (int i = 0; i < 16; i++) slot[i * T + c.t] = v[i];
+  }
+}
+// The accumulate of ph_pass3_acc over frames [0, K) from their slots (slot f at park_base + f slot_bytes), same operations, same order.
+template <class C>
+CRN_DEV void replay_parked(FrameCtx<C> &c, unsigned park_base, int K) {
+  constexpr int T = Geo<C::R3>::T;
+  constexpr unsigned kSlotBytes = (unsigned)Geo<C::R3>::N * (C::MAG ? 4u : 8u);
+  for (int f = 0; f < K; f++) {
+    const unsigned off = park_base + (unsigned)f * kSlotBytes;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if constexpr (C::MAG) {
+        const float mag = reinterpret_cast<const lds_park_f32 *>(off)[i * T + c.t];
+        c.acc[i] = fmaf(mag, c.invK, c.acc[i]);
+      } else {
+        const cx x = reinterpret_cast<const lds_park_cx *>(off)[i * T + c.t];
+        c.acc[i] = fmaf(x.y, x.y, fmaf(x.x, x.x, c.acc[i]));
+      }
+    }
+  }
+}
+
 // pass 3 + per-bin accumulate: v[j * R3 + d] is bin a + 16 (m_lo J + j) + 256 d
 template <class C>
 CRN_DEV void ph_pass3_acc(cx (&u)[16], FrameCtx<C> &c) {
+  if constexpr ((C::OPT & kDeal) != 0) {
+    ph_pass3_park<C>(u, c);
+    return;
+  }
 #ifdef CRN_AB_VARIANTS
   if constexpr ((C::OPT & kRowsRT) != 0 && C::R3 == 16) {
     ph_pass3_acc_rt<C>(u, c);
@@ -635,7 +683,6 @@ CRN_DEV void frame_compute(cx (&u)[16], FrameCtx<C> &c, int f, cx (*nx)[16] = nu
 // pair shares its s_barriers (one per frame instead of two).  Needs NBUF == 2.
 template <class C>
 CRN_DEV void frame_pair_compute(cx (&ua)[16], cx (&ub)[16], FrameCtx<C> &c) {
-  using G = Geo<C::R3>;
   static_assert(C::NBUF == 2, "the frame pair uses one exchange buffer per frame");
   cx *bufa = c.gbuf, *bufb = c.gbuf + Lay<C>::GROUP_CPLX;
   cx va[16], vb[16];

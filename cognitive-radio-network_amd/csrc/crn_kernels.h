@@ -49,6 +49,8 @@ struct SenseParams {
   int hann_sym;            // the window table is a periodic Hann: w[n + N/2] = 1 - w[n] (may be folded into pass 1)
   unsigned acc_mask;       // bit j R3 + d set when some band holds a bin of the form a + 16 (g J + j) + 256 d, i.e. when accumulator
                            // register j R3 + d of some thread holds a band bin (N = 4096: bit d = the 256-bin row d)
+  int deal_rounds;         // > 0: sense_kernel_dealt (one epoch per workgroup, its frames dealt to the lane groups, this many rounds of them);
+                           // set by the host for launches of a few epochs at N <= 1024 without a window (crn_api.cpp)
   float wire_unscale;      // wire-format launches: 1 / full scale (2^-15 by default) for a sum of magnitudes, its square for energies
   // outputs (device, nullable)
   float *features;
@@ -83,6 +85,9 @@ struct SynthParams {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream, bool sc16 = false);
 int sense_num_variants();
+// Rounds of dealt frames (ceil(K / lane groups)) when sense_kernel_dealt can take this size / mode / K — N <= 1024 and the frame
+// slots fit in LDS — else 0.
+int sense_deal_rounds(int fft_len, bool mag, int frames_per_epoch);
 unsigned sense_ref_acc_mask(int fft_len);    // accumulator registers (bit j R3 + d) the reference channel plan reaches at this size
 bool sense_variant_available(int variant);   // the shipped library carries 0 (= 13), 2 and 23; libcrnsense_ab.so all of them
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);

@@ -67,6 +67,9 @@ static constexpr int kDefaultVariant = 13;
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
+  if constexpr (R3 <= 4) {   // a launch of a few epochs (crn_api.cpp sets deal_rounds): one epoch per workgroup, frames dealt to its lane groups
+    if (p.deal_rounds > 0 && !win) return launch_dealt<R3, 0>(p, mag, stream);
+  }
 #ifdef CRN_AB_VARIANTS
   if constexpr (R3 == 16) {
     if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && variant >= 25 && variant <= 27) {
@@ -190,6 +193,15 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 }
 
 int sense_num_variants() { return kNumVariants; }
+
+int sense_deal_rounds(int fft_len, bool mag, int K) {
+  if (fft_len != 512 && fft_len != 1024) return 0;
+  const int r3 = fft_len / 256, t = 16 * r3, groups = 256 / t;
+  if (K < 2) return 0;   // one frame: nothing to deal
+  const int rounds = (K + groups - 1) / groups;
+  const size_t lds = ((size_t)groups * 16 * (t + r3) + 16 * r3) * sizeof(cx) + kCloseLdsBytes + (size_t)rounds * groups * fft_len * (mag ? 4 : 8);
+  return lds <= 160 * 1024 ? rounds : 0;
+}
 unsigned sense_ref_acc_mask(int fft_len) { return ref_acc_mask(fft_len / 256); }
 
 // Does this build of the library carry variant v?  (0 = default.)

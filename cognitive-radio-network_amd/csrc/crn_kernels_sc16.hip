@@ -9,6 +9,9 @@ namespace crn {
 template <int R3>
 static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
+  if constexpr (R3 <= 4) {   // a launch of a few epochs: frames dealt to the workgroup's lane groups (sense_kernel_dealt)
+    if (p.deal_rounds > 0 && !win) return launch_dealt<R3, kSc16>(p, mag, stream);
+  }
   if (win) {
     // everything that is not the Welch configuration's kernel: the generic windowed kernels (window table in registers)
     if (mag || !p.hann_sym || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2, false>(p, mag, win, stream);

@@ -337,6 +337,132 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// the sensing kernel for launches of a few epochs (the engine's shape: ONE epoch of ten 512-point frames, reference
+// CE_Predictive_Node.cpp:148-156 run once per sensing period)
+// ---------------------------------------------------------------------------------------------
+// sense_kernel gives an epoch to one lane group and runs its K frames one after the other — the right shape when thousands of epochs
+// fill the machine, but a single epoch then occupies T of a workgroup's 256 threads for K dependent frame latencies while the other
+// lane groups idle.  Here a workgroup takes ONE epoch and deals its frames to its GROUPS lane groups (group g: frames g, g + GROUPS,
+// ...): ceil(K / GROUPS) frame latencies instead of K.  Every frame's per-bin values are parked in LDS (ph_pass3_park); after one
+// barrier lane group 0 replays the accumulate from the slots in frame order — the same operations in the same order as the
+// streaming kernel, so features, network outputs and decisions are bit for bit the same — and closes the epoch as usual.
+// Sizes whose frames stay inside one wave (N <= 1024: no workgroup barrier inside a frame); no window.
+template <class C>
+__global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p) {
+  constexpr int R3 = C::R3;
+  constexpr bool NT = C::NT, SC = C::SC16;
+  constexpr unsigned SB = C::SB;
+  using G = Geo<R3>;
+  constexpr int T = G::T;
+  static_assert(!G::XWAVE && !C::WIN && C::NBUF == 1 && !C::TW2LDS && (C::OPT & kDeal) != 0 && (C::OPT & kSpread) != 0 && C::ABL == 0,
+                "dealt frames: N <= 1024, no window, twiddles in registers");
+  extern __shared__ __attribute__((aligned(16))) cx lds[];
+
+  const int tid = threadIdx.x;
+  const int grp = tid / T;
+  const int t = tid % T;
+
+  FrameCtx<C> c;
+  c.t = t;
+  c.a = t / R3;
+  c.m_lo = t % R3;
+  c.L = p.L;
+  c.rt_mask = 0xFFFFu;
+  c.gbuf = lds + grp * Lay<C>::GROUP_CPLX;
+  c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
+  c.tw2_lds = lds + G::GROUPS * Lay<C>::GROUP_CPLX;
+  // only lane group 0 holds an epoch when the close runs: the others' epoch index lands past the batch (inactive)
+  c.grp_epoch_stride = (int)p.n_epochs;
+  const int K = p.K;
+  c.Kf = (float)K;
+  c.invK = 1.0f / (float)K;
+
+  // this epoch's samples: anything past the epoch's last frame, or past the batch, reads as zero
+  const long long first = (long long)blockIdx.x * p.epoch_stride;
+  long long left = (p.total_samples - first) * SB;
+  const long long window = ((long long)(K - 1) * p.frame_stride + G::N) * SB;
+  if (left > window) left = window;
+  if (left < 0) left = 0;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(const_cast<float2 *>(p.iq)) + first * SB, 0, (int)left, 0x00020000);
+  const unsigned voff = (unsigned)t * SB;
+  const unsigned fbytes = (unsigned)p.frame_stride * SB;
+  constexpr unsigned kNowhere = 0x80000000u;
+  const int rounds = p.deal_rounds;            // ceil(K / GROUPS): every lane group runs that many frames (uniform wave barriers;
+                                               // a frame index >= K loads zeros into a slot the replay never reads)
+  cx ua[16], ub[16];
+  load_frame<R3, NT, SC>(ua, rs, voff, grp < K ? (unsigned)grp * fbytes : kNowhere, c.L);
+
+#pragma unroll
+  for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
+#pragma unroll
+  for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + c.m_lo];
+  {
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * Lay<C>::GROUP_CPLX + 16 * R3);
+    const int w0 = p.band_tab[tid], w1 = p.band_tab[tid + 256];
+    const int w2 = p.band_tab[tid < kBandTabWords - 512 ? tid + 512 : kBandTabWords - 1];
+    tab[tid] = w0;
+    tab[tid + 256] = w1;
+    if (tid < kBandTabWords - 512) tab[tid + 512] = w2;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
+
+  // frame slots behind everything the streaming kernel keeps in LDS: [rounds x GROUPS][16][T] values
+  constexpr unsigned kSlotBytes = (unsigned)G::N * (C::MAG ? 4u : 8u);
+  const unsigned park_base =
+      c.lds_base + (unsigned)((G::GROUPS * Lay<C>::GROUP_CPLX + 16 * R3) * sizeof(cx)) + (unsigned)kCloseLdsBytes;
+  int r = 0;
+#define CRN_DEAL_STEP(CUR, NXT)                                                                       \
+  {                                                                                                   \
+    const int f = r * G::GROUPS + grp, fn = f + G::GROUPS;                                            \
+    c.park_off = park_base + (unsigned)f * kSlotBytes;                                                \
+    frame_compute<C, true>(CUR, c, 0, &NXT, rs, voff, (r + 1 < rounds && fn < K) ? (unsigned)fn * fbytes : kNowhere); \
+    r++;                                                                                              \
+  }
+  while (true) {
+    CRN_DEAL_STEP(ua, ub)
+    if (r >= rounds) break;
+    CRN_DEAL_STEP(ub, ua)
+    if (r >= rounds) break;
+  }
+#undef CRN_DEAL_STEP
+  __syncthreads();   // every frame of the epoch is parked (and the band table is in place)
+  if (grp == 0) replay_parked<C>(c, park_base, K);
+  epoch_close<C>(c, p, (long long)blockIdx.x);
+}
+
+template <class C>
+static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
+  using G = Geo<C::R3>;
+  const size_t slot_bytes = (size_t)G::N * (C::MAG ? 4 : 8);
+  const size_t lds = ((size_t)G::GROUPS * Lay<C>::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes +
+                     (size_t)p.deal_rounds * G::GROUPS * slot_bytes;
+  if (p.n_epochs <= 0) return hipSuccess;
+  auto kfn = sense_kernel_dealt<C>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)p.n_epochs), dim3(256), lds, stream, p);
+  return hipGetLastError();
+}
+
+// Dealt-frame forms of a size: |X| or energy, band sums from registers or through the LDS walk; short frames are masked at run time.
+template <int R3, int OPT>
+static hipError_t launch_dealt(const SenseParams &p, bool mag, hipStream_t stream) {
+  constexpr int kO = kSpread | kLdsBlk | kDeal | OPT;
+  const bool regb = p.n_row_entries > 0 && p.spectrum == nullptr;
+  if (mag) {
+    if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, 0, false, true, kO | kRegBands>>(p, stream);
+    return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, 0, false, true, kO>>(p, stream);
+  }
+  if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, 0, false, true, kO | kRegBands>>(p, stream);
+  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, 0, false, true, kO>>(p, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch dispatch
 // ---------------------------------------------------------------------------------------------
 template <class C>

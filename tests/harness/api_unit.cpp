@@ -61,6 +61,13 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
   return hipSuccess;
 }
 int sense_num_variants() { return 24; }
+// (the rule of csrc/crn_kernels.hip restated: frames of 512 / 1024 points, K >= 2, the frame slots within 160 KiB of LDS)
+int sense_deal_rounds(int fft_len, bool mag, int K) {
+  if ((fft_len != 512 && fft_len != 1024) || K < 2) return 0;
+  const int groups = 256 / (fft_len / 16), rounds = (K + groups - 1) / groups;
+  const size_t fixed = fft_len == 512 ? 8 * 16 * 34 * 8 + 32 * 8 + 3136 : 4 * 16 * 68 * 8 + 64 * 8 + 3136;
+  return fixed + (size_t)rounds * groups * fft_len * (mag ? 4 : 8) <= 160 * 1024 ? rounds : 0;
+}
 // the masks csrc/crn_butterflies.h derives from the reference channel plan (ref_acc_mask): restated here from the plan itself, below
 unsigned sense_ref_acc_mask(int fft_len) { return fft_len == 512 ? 0x85e1u : fft_len == 1024 ? 0xbf73u : fft_len == 2048 ? 0x9f9bu : 0x8267u; }
 bool sense_variant_available(int v) { return v == 0 || v == 13 || v == 2 || v == 23; }   // the shipped library's set
@@ -252,14 +259,33 @@ static void test_geometry() {
         cfg.frames_per_epoch = K;
         crn_handle *h = nullptr;
         REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+        int64_t dealt_before = 0, dealt_after = 0;
+        REQUIRE(crn_sense_dealt_launches(h, &dealt_before) == CRN_OK && dealt_before == 0);
         for (long long E : epochs) {
           const crn::SenseParams p = launch(h, E, N);
           check_coverage(p, N, "plain");
+          // the dealt-frame form: launches of up to one epoch per compute unit, 512 / 1024 points, at least two frames
+          const int groups = 256 / (N / 16);
+          const int fits = crn::sense_deal_rounds(N, false, K);   // 0 when the K frame slots do not fit in LDS (K = 32 here)
+          REQUIRE(fits == 0 || fits == (K + groups - 1) / groups);
+          REQUIRE((fits > 0) == ((N == 512 || N == 1024) && K >= 2 && K <= 10));
+          const bool want_deal = fits > 0 && E <= (long long)n_cus;
+          REQUIRE(p.deal_rounds == (want_deal ? fits : 0));
+          dealt_before += want_deal;
+          // ... switched off and forced (A/B codes 401 / 402), and back to automatic
+          REQUIRE(crn_sense_set_variant(h, 401) == CRN_OK);
+          REQUIRE(launch(h, E, N).deal_rounds == 0);
+          REQUIRE(crn_sense_set_variant(h, 402) == CRN_OK);
+          const bool can = fits > 0;
+          REQUIRE((launch(h, E, N).deal_rounds > 0) == can);
+          dealt_before += can;
+          REQUIRE(crn_sense_set_variant(h, 400) == CRN_OK);
           REQUIRE(p.groups_per_wg >= 1 && p.groups_per_wg <= 4 && p.tail_groups_per_wg == 1);
           const long long n_groups = (E + 256 / (N / 16) - 1) / (256 / (N / 16));
           REQUIRE(n_groups - p.n_big_wgs * p.groups_per_wg <= std::max<long long>(n_groups / 4, 0) + p.groups_per_wg);   // the single-group tail is at most a quarter
           REQUIRE(p.total_samples == (E - 1) * (long long)K * N + (long long)K * N);
         }
+        REQUIRE(crn_sense_dealt_launches(h, &dealt_after) == CRN_OK && dealt_after == dealt_before);
         // geometry overrides (A/B codes) keep the coverage
         REQUIRE(crn_sense_set_variant(h, 100 + 7) == CRN_OK);
         REQUIRE(crn_sense_set_variant(h, 200 + 3) == CRN_OK);
@@ -318,7 +344,7 @@ static void test_arguments_and_counters() {
   // the shipped variant policy
   REQUIRE(crn_sense_set_variant(h, 7) == CRN_ERR_ARG && std::strstr(crn_last_error(), "measurement variant") != nullptr);
   REQUIRE(crn_sense_set_variant(h, 23) == CRN_OK && crn_sense_set_variant(h, 0) == CRN_OK);
-  REQUIRE(crn_sense_set_variant(h, 400) == CRN_ERR_ARG && crn_sense_set_variant(h, -1) == CRN_ERR_ARG);
+  REQUIRE(crn_sense_set_variant(h, 403) == CRN_ERR_ARG && crn_sense_set_variant(h, -1) == CRN_ERR_ARG);
   // live updates reach the next launch's tables
   float thr[4] = {9.f, 8.f, 7.f, 6.f};
   REQUIRE(crn_sense_set_thresholds(h, thr, 4, nullptr) == CRN_OK);

@@ -1,7 +1,9 @@
 """The C oracle against the independent float64 restatement (tests/ref_f64.py) on RANDOM plans — beyond the committed fixtures: any
 band table (several runs per band, overlapping bands, a band that wraps around DC), magnitude or energy mode, rectangular / Hann /
 Blackman-Harris window, Welch hop or disjoint frames, short packets, K from 1 to 12, absolute or reference-band thresholds.
-Features to 1e-5 (the parity bar), occupancy exactly wherever float64 leaves a margin.  No GPU."""
+Features to 1e-5 (the parity bar), occupancy exactly wherever float64 leaves a margin.  The CPU cases draw fresh examples every run;
+the GPU cases run a fixed (derandomized) set, so that the round-end GPU suite is the same suite every time — fresh random
+configurations on the GPU are tests/soak_gpu.py's job (seeds stated, profiles/r04_soak.txt)."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -94,7 +96,7 @@ def test_oracle_matches_float64_on_random_plans(built, p):
 
 
 @pytest.mark.gpu
-@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(plans())
 def test_gpu_matches_float64_on_random_plans(built, p):
     """The HIP path through the C ABI against the same independent float64 restatement, same random plans, same bars."""
@@ -146,7 +148,7 @@ def test_oracle_reference_mode_on_random_traffic(built, t):
 
 
 @pytest.mark.gpu
-@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(ref_traffic())
 def test_gpu_reference_mode_on_random_traffic(built, t):
     iq, n_epochs, L = _ref_case(t)

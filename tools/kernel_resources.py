@@ -8,7 +8,7 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else "cognitive-radio-network_amd/csrc/build/resource_usage.txt"
 txt = open(path).read()
 FLAGS = {2: 'Pair', 4: 'Spread', 32: 'LdsBlk', 64: 'Tw1C', 128: 'Fence', 256: 'Rows', 512: 'Multi', 1024: 'Prio', 2048: 'NoClose', 262144: 'RowsRT', 524288: 'X2Wide',
-         4096: 'Trace', 8192: 'RegB', 16384: 'HannSym', 32768: 'Tw2E', 65536: 'Aligned', 131072: 'Sc16'}
+         4096: 'Trace', 8192: 'RegB', 16384: 'HannSym', 32768: 'Tw2E', 65536: 'Aligned', 131072: 'Sc16', 1048576: 'Deal'}
 K_V, K_S, K_X, K_O = "VGPRs", "SGPRs", r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
 bad = 0
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
