@@ -1,6 +1,8 @@
 // crn_sense_kernel.h — the sensing kernel itself (the frame loop in its streaming forms) and its launch helpers.
 #ifndef CRN_SENSE_KERNEL_H
 #define CRN_SENSE_KERNEL_H
+#include <atomic>
+
 #include "crn_epoch_close.h"
 
 namespace crn {
@@ -442,8 +444,16 @@ static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
   if (p.n_epochs <= 0) return hipSuccess;
   auto kfn = sense_kernel_dealt<C>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    // once per kernel, device and size: this is the engine's launch, repeated every sensing period with the same K
+    static std::atomic<size_t> allowed[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t> &a = allowed[dev & 63];
+    if (a.load(std::memory_order_acquire) < lds) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      a.store(lds, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)p.n_epochs), dim3(256), lds, stream, p);
   return hipGetLastError();
