@@ -565,8 +565,8 @@ typedef struct crn_sense_stats {
 CRN_API int crn_sense_set_timing(crn_handle *h, int32_t on);
 CRN_API int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out);
 
-/* Launches of a few epochs — up to one per compute unit; the engine's launch is ONE — at fft_len 512 / 1024 without a window run the
- * sensing kernel in its dealt-frame form: one epoch per workgroup, its frames_per_epoch frames spread over the workgroup's lane
+/* Launches of a few epochs — up to one per compute unit; the engine's launch is ONE — at fft_len 512 / 1024 (any window, disjoint or
+ * overlapped frames) run the sensing kernel in its dealt-frame form: one epoch per workgroup, its frames_per_epoch frames spread over the workgroup's lane
  * groups (8 at 512 points, 4 at 1024) instead of run one after the other by one of them, the K-frame accumulate replayed in frame
  * order afterwards: the same operations in the same order, so every output is bit for bit what the streaming form gives, in about
  * ceil(K / groups) frame latencies instead of K.  Chosen per launch from n_epochs; *n = how many launches of this handle ran that

@@ -595,7 +595,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // HBM and 29.4 -> 15.4 from pinned host memory (the ring's launch); 256 epochs 20.3 -> 10.9; from 512 epochs on — two
     // workgroups per CU — the energy forms lose (17.5 -> 20.5), so the switch sits at one per CU.
     const int64_t deal_max = h->deal_max_epochs >= 0 ? h->deal_max_epochs : (int64_t)h->n_cus;
-    if (n_epochs <= deal_max && c.window == CRN_WINDOW_RECT && (h->variant == 0 || h->variant == 13))
+    if (n_epochs <= deal_max && (h->variant == 0 || h->variant == 13))
       p.deal_rounds = crn::sense_deal_rounds(c.fft_len, c.mode == CRN_MODE_REF_MAG, c.frames_per_epoch);
   }
   p.tw1 = h->d_tw1;

@@ -50,7 +50,7 @@ struct SenseParams {
   unsigned acc_mask;       // bit j R3 + d set when some band holds a bin of the form a + 16 (g J + j) + 256 d, i.e. when accumulator
                            // register j R3 + d of some thread holds a band bin (N = 4096: bit d = the 256-bin row d)
   int deal_rounds;         // > 0: sense_kernel_dealt (one epoch per workgroup, its frames dealt to the lane groups, this many rounds of them);
-                           // set by the host for launches of a few epochs at N <= 1024 without a window (crn_api.cpp)
+                           // set by the host for launches of a few epochs at N <= 1024 (crn_api.cpp)
   float wire_unscale;      // wire-format launches: 1 / full scale (2^-15 by default) for a sum of magnitudes, its square for energies
   // outputs (device, nullable)
   float *features;

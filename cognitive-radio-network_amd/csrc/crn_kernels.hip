@@ -68,7 +68,7 @@ template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
   if constexpr (R3 <= 4) {   // a launch of a few epochs (crn_api.cpp sets deal_rounds): one epoch per workgroup, frames dealt to its lane groups
-    if (p.deal_rounds > 0 && !win) return launch_dealt<R3, 0>(p, mag, stream);
+    if (p.deal_rounds > 0) return win ? launch_dealt_win<R3, 0>(p, mag, stream) : launch_dealt<R3, 0>(p, mag, stream);
   }
 #ifdef CRN_AB_VARIANTS
   if constexpr (R3 == 16) {

@@ -10,7 +10,7 @@ template <int R3>
 static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
   if constexpr (R3 <= 4) {   // a launch of a few epochs: frames dealt to the workgroup's lane groups (sense_kernel_dealt)
-    if (p.deal_rounds > 0 && !win) return launch_dealt<R3, kSc16>(p, mag, stream);
+    if (p.deal_rounds > 0) return win ? launch_dealt_win<R3, kSc16>(p, mag, stream) : launch_dealt<R3, kSc16>(p, mag, stream);
   }
   if (win) {
     // everything that is not the Welch configuration's kernel: the generic windowed kernels (window table in registers)

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
 // ...): ceil(K / GROUPS) frame latencies instead of K.  Every frame's per-bin values are parked in LDS (ph_pass3_park); after one
 // barrier lane group 0 replays the accumulate from the slots in frame order — the same operations in the same order as the
 // streaming kernel, so features, network outputs and decisions are bit for bit the same — and closes the epoch as usual.
-// Sizes whose frames stay inside one wave (N <= 1024: no workgroup barrier inside a frame); no window.
+// Sizes whose frames stay inside one wave (N <= 1024: no workgroup barrier inside a frame).  Overlapped frames (the Welch plans) are
+// fetched whole by their lane group: a half-frame two groups share is read twice, from L2 the second time.
 template <class C>
 __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p) {
   constexpr int R3 = C::R3;
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
   constexpr unsigned SB = C::SB;
   using G = Geo<R3>;
   constexpr int T = G::T;
-  static_assert(!G::XWAVE && !C::WIN && C::NBUF == 1 && !C::TW2LDS && (C::OPT & kDeal) != 0 && (C::OPT & kSpread) != 0 && C::ABL == 0,
-                "dealt frames: N <= 1024, no window, twiddles in registers");
+  static_assert(!G::XWAVE && C::NBUF == 1 && !C::TW2LDS && (C::OPT & kDeal) != 0 && (C::OPT & kSpread) != 0 && C::ABL == 0,
+                "dealt frames: N <= 1024, twiddles in registers");
   extern __shared__ __attribute__((aligned(16))) cx lds[];
 
   const int tid = threadIdx.x;
@@ -400,6 +401,13 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
   for (int i = 1; i < 16; i++) c.tw1[i] = reinterpret_cast<const cx *>(p.tw1)[i * T + t];
 #pragma unroll
   for (int i = 1; i < 16; i++) c.tw2[i] = reinterpret_cast<const cx *>(p.tw2)[i * R3 + c.m_lo];
+  if constexpr (C::WIN && (C::OPT & kHannSym) != 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) c.winp[q] = cx{p.window[t + T * (2 * q)], p.window[t + T * (2 * q + 1)]};
+  } else if constexpr (C::WIN) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
+  }
   {
     int *tab = reinterpret_cast<int *>(lds + G::GROUPS * Lay<C>::GROUP_CPLX + 16 * R3);
     const int w0 = p.band_tab[tid], w1 = p.band_tab[tid + 256];
@@ -457,6 +465,18 @@ static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)p.n_epochs), dim3(256), lds, stream, p);
   return hipGetLastError();
+}
+
+// Windowed dealt-frame forms, mirroring what the streaming dispatch picks for the same launch (so that the arithmetic is the same,
+// bit for bit): periodic Hann on whole frames in energy mode rides in pass 1's first butterflies (kHannSym); every other window,
+// mode and frame length multiplies by the table.  Windowed kernels close through the LDS walk.
+template <int R3, int OPT>
+static hipError_t launch_dealt_win(const SenseParams &p, bool mag, hipStream_t stream) {
+  constexpr int kO = kSpread | kLdsBlk | kDeal | OPT;
+  if (!mag && p.hann_sym && p.L == Geo<R3>::N)
+    return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, 0, false, true, kO | kHannSym>>(p, stream);
+  if (mag) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, true, false, 1, 0, false, true, kO>>(p, stream);
+  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, 0, false, true, kO>>(p, stream);
 }
 
 // Dealt-frame forms of a size: |X| or energy, band sums from registers or through the LDS walk; short frames are masked at run time.

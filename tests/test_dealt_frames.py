@@ -1,5 +1,5 @@
 """The dealt-frame form of the sensing kernel (csrc/crn_sense_kernel.h: sense_kernel_dealt) — what a launch of a few epochs runs at
-512 / 1024 points without a window, the engine's one-epoch launch first of all (reference: one epoch of ten 512-point frames per
+512 / 1024 points (any window), the engine's one-epoch launch first of all (reference: one epoch of ten 512-point frames per
 sensing period, CE_Predictive_Node.cpp:148-156).  An epoch's frames are spread over the lane groups of one workgroup and the K-frame
 accumulate is replayed in frame order afterwards, so every output must be BIT FOR BIT what the streaming form gives on the same
 input: that equality is the test (the streaming form's parity with the oracle is everything else in tests/), plus the oracle directly
@@ -65,6 +65,50 @@ def test_dealt_frames_equal_the_streaming_kernel(built, n):
         iq, _ = signals.make_epochs(cfg, 3, seed=n + 99, L=n)
         a, b = _both(cfg, iq, 3, n, want_spectrum=True)
         _same(a, b, ["features", "occupancy", "spectrum"])
+
+
+def _windowed(n):
+    yield "Welch: periodic Hann, hop N/2, 64 bands (window folded into pass 1)", cs.cfg_welch(n, 8, 64), (n,)
+    yield "Welch, 16 bands", cs.cfg_welch(n, 5, 16), (n,)
+    c = cs.cfg_energy_scaled(n, 4.0)
+    c.window = cs.WINDOW_HANN                              # disjoint Hann frames: still the folded form on whole frames, the table on short ones
+    yield "Hann, disjoint frames", c, (n, 364, 100)
+    c = cs.cfg_energy_scaled(n, 4.0)
+    c.window = cs.WINDOW_BLACKMAN_HARRIS
+    yield "Blackman-Harris (table window)", c, (n, 364)
+    c = cs.cfg_welch(n, 8, 64)
+    c.mode = cs.MODE_REF_MAG
+    yield "Welch on magnitudes", c, (n,)
+    c = cs.cfg_reference_scaled(n)
+    c.window = cs.WINDOW_HANN
+    yield "reference mode behind a Hann window", c, (n, 364)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 1024])
+def test_windowed_dealt_frames_equal_the_streaming_kernel(built, n):
+    """Windows and overlapped frames (the engine's -m welch / -m scan at its default size): each lane group fetches its whole frame,
+    the window is applied the way the streaming dispatch applies it for the same launch, so the outputs are again bit-identical."""
+    for name, base, Ls in _windowed(n):
+        for K in (2, 5, 8, 10):
+            for L in Ls:
+                for n_epochs in (1, 4):
+                    cfg = base
+                    cfg.frames_per_epoch = K
+                    for b in range(cfg.n_bands):
+                        if cfg.decide == cs.DECIDE_THRESHOLD and cfg.ref_band < 0:
+                            cfg.thresh[b] = 1e-3
+                    iq, _ = signals.make_epochs(cfg, n_epochs, seed=3 * n + 11 * K + L, L=L)
+                    a, b = _both(cfg, iq, n_epochs, L)
+                    keys = ["features", "occupancy"] + (["ann_out", "decision"] if cfg.decide == cs.DECIDE_ANN else [])
+                    _same(a, b, keys)
+        cfg = base
+        cfg.frames_per_epoch = 8
+        iq, _ = signals.make_epochs(cfg, 3, seed=n + 7, L=n)
+        a, b = _both(cfg, iq, 3, n, want_spectrum=True)
+        _same(a, b, ["features", "occupancy", "spectrum"])
+        want = orc.run(cfg, iq, 3, L=n)
+        assert np.allclose(b["features"], want["features"], rtol=1e-5, atol=0), name
 
 
 @pytest.mark.gpu

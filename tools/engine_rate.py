@@ -17,3 +17,17 @@ for name, mode in (("enqueue-only (default)", []), ("synchronous (-a 0)", ["-a",
     for ln in out.stdout.splitlines():
         if ln.startswith("execute_us") or ln.startswith("epoch_closing") or ln.startswith("CE_Predictive_Node_GPU:"):
             print("   ", ln)
+# the extension modes at the engine's default size (512 points): Welch estimate on the reference's channels, and the 64-band scan with
+# its start-up calibration — one epoch per launch as well (windowed, overlapped frames: the dealt-frame kernel's windowed forms)
+rng = np.random.default_rng(6)
+for name, mode, K in (("-m welch", ["-m", "welch"], 10), ("-m scan -c 8", ["-m", "scan", "-c", "8"], 8)):
+    P = -(-((K - 1) * 256 + 512) // L)
+    n_ep = 2000
+    noise = rng.normal(0, 7e-4, n_ep * P * L * 2).astype(np.float32)
+    noise.tofile("/tmp/iq_rate_w.bin")
+    out = subprocess.run(["tests/harness/engine_harness", "/tmp/iq_rate_w.bin", str(L), "-g", "0", "-v", "0", "-s", "1"] + mode, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("epoch ")]
+    print(f"engine {name} (enqueue-only, {P} packets of {L} samples per epoch): {len(lines)} epochs decided")
+    for ln in out.stdout.splitlines():
+        if ln.startswith("epoch_closing") or ln.startswith("CE_Predictive_Node_GPU:"):
+            print("   ", ln)

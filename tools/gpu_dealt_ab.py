@@ -48,10 +48,14 @@ def single_launch_us(s, ptr, E, L, outs):
 
 lines = []
 for label, cfg, L in (("reference 512-pt, |X| + network, 364-sample packets (the engine's shape)", cs.cfg_reference(), 364),
+                      ("512-pt Welch scan: periodic Hann, hop 256, K = 8, 64 bands (the engine's -m scan at its default size)", cs.cfg_welch(512, 8, 64), 512),
                       ("512-pt energy detect, whole frames", cs.cfg_energy_scaled(512, 4.0), 512),
                       ("1024-pt energy detect, whole frames", cs.cfg_energy_scaled(1024, 4.0), 1024)):
     lines.append(label)
     lines.append(f"  {'epochs':>7} {'streaming us':>13} {'dealt us':>9} {'ratio':>6}   {'lone launch: streaming us':>26} {'dealt us':>9}")
+    for b in range(cfg.n_bands):
+        if cfg.decide == cs.DECIDE_THRESHOLD and cfg.ref_band < 0:
+            cfg.thresh[b] = 1e-3
     for E in (1, 2, 8, 32, 128, 256, 512, 1024, 2048, 4096):
         need = cs.samples_needed(cfg, E, L)
         iq = (torch.randn(need * 2, device=dev) * 1e-2).contiguous()
