@@ -243,7 +243,12 @@ CRN_API int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t wa
  * wait for the GPU and never allocate: `execute()` only copies one packet and checks an event.
  * The ring owns a launcher thread that makes every HIP call (it calls crn_sense_run_device on the
  * handle: do not use crn_sense_run_host / crn_sense_reserve_host on that handle from another
- * thread while batches are in flight; crn_sense_run_device is safe to call concurrently). */
+ * thread while batches are in flight; crn_sense_run_device is safe to call concurrently).
+ * Environment, read at creation: $CRN_INGEST_ZEROCOPY_BYTES (524288: batches up to this size are read from and written to the
+ * pinned buffers by the kernel itself, no copies), $CRN_INGEST_SPIN_US (150: how long after a small batch's hand-off the launcher
+ * polls its event before sleeping), $CRN_INGEST_PREWAKE_US (600; 0 = off: ten packets before a small batch's hand-off the pushing
+ * thread tells the launcher — one condition-variable signal, no wait — and the launcher polls for the work for at most this long
+ * instead of sleeping: a sleeping thread comes back tens of microseconds late). */
 typedef struct crn_ingest crn_ingest;
 
 typedef struct crn_epoch_result {

@@ -61,6 +61,7 @@ struct Batch {
   std::vector<Slot> slots;      // [C]
   int assigned = 0;             // slots handed to streams, in order of epoch start
   int complete = 0;             // of which hold all K packets
+  int staged = 0;               // packets staged in this buffer (with the packets of epochs carried over from the other one)
   int launched = 0;             // slots of the launch handed to the launcher thread
   int L = 0, P = 0;             // packet length and packets per epoch of that launch
   bool calibrating = false;     // launched while a calibration was collecting or before its thresholds were in place (launcher thread)
@@ -100,6 +101,14 @@ struct crn_ingest {
   size_t zero_copy_bytes = 512 * 1024;     // batches up to this size are read / written in place by the kernel
   int spin_us = 150;                       // how long after a hand-off the launcher keeps polling before it sleeps ($CRN_INGEST_SPIN_US)
   std::atomic<bool> work_waiting{false};   // work is not empty (read by the launcher without the lock while it polls an event)
+  // Pre-wake: a sleeping launcher thread needs tens of microseconds to come back (63 us from hand-off to decision with the GPU and
+  // the thread idle for 100 ms between epochs, against 37 us back to back: tools/engine_idle_gap.py).  With a small batch — the
+  // engine's one epoch — the first packet of a batch tells the launcher that a hand-off is K packet times away (280 us at 13 Msps):
+  // it wakes up now and polls for the work instead of sleeping, for at most prewake_us ($CRN_INGEST_PREWAKE_US, 0 = never).
+  std::atomic<bool> prewake{false};
+  int prewake_us = 600;
+  int prewake_at = 0;                      // packets staged in a batch at which the launcher is told (0 = never): B P - 10, at least 1 — ten
+                                           // packets before the hand-off (280 us at 13 Msps), only for batches small enough for the in-place launch
   int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
   double lat_us_sum = 0.0, lat_us_max = 0.0;
   // ---- noise-floor calibration (crn_ingest_calibrate): requested by the caller's thread, carried out by the launcher ----
@@ -127,6 +136,20 @@ int packets_per_epoch(const crn_cfg &c, int L) {
   if (c.hop == c.fft_len) return c.frames_per_epoch;
   const long long span = (long long)(c.frames_per_epoch - 1) * c.hop + c.fft_len;
   return (int)((span + L - 1) / L);
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+
+void set_prewake(crn_ingest *g) {
+  const long long total = (long long)g->B * g->P;
+  const bool small = (size_t)g->B * g->epoch_bytes <= g->zero_copy_bytes;
+  g->prewake_at = (small && total > 1 && g->prewake_us > 0) ? (int)std::max<long long>(total - 10, 1) : 0;
 }
 
 // ---- launcher thread -------------------------------------------------------------------------
@@ -209,7 +232,7 @@ std::string feed_calibration(crn_ingest *g, const std::vector<crn_epoch_result> 
 
 // Give a batch back to the caller's thread (mu held).
 void release_batch(crn_ingest *g, Batch &b) {
-  b.assigned = b.complete = b.launched = 0;
+  b.assigned = b.complete = b.launched = b.staged = 0;
   b.state.store(kFree, std::memory_order_release);
   g->cv_free.notify_all();
 }
@@ -242,6 +265,15 @@ void launcher_main(crn_ingest *g) {
     }
     if (inflight.empty()) {
       if (g->stop) return;
+      if (g->prewake.exchange(false, std::memory_order_acq_rel)) {
+        // a batch has started to fill: stay awake for its hand-off (bounded; the pushing thread never waits for this)
+        lk.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds(g->prewake_us);
+        while (!g->work_waiting.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - t0 < budget) cpu_relax();
+        lk.lock();
+        continue;
+      }
       g->cv_work.wait(lk);
       continue;
     }
@@ -326,6 +358,7 @@ int launch(crn_ingest *g) {
       if (sl.stream < 0 || sl.npk == g->P) continue;
       const int j = o.assigned++;
       o.slots[j] = sl;
+      o.staged += sl.npk;
       std::memcpy(o.h_iq + (size_t)j * g->epoch_bytes, b.h_iq + (size_t)i * g->epoch_bytes, (size_t)sl.npk * g->L * g->sample_bytes);
       g->open_slot[sl.stream] = j;
       sl.stream = -1;
@@ -416,6 +449,8 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   }
   if (const char *e = std::getenv("CRN_INGEST_SPIN_US")) g->spin_us = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("CRN_INGEST_ZEROCOPY_BYTES")) g->zero_copy_bytes = (size_t)std::max(0ll, std::atoll(e));
+  if (const char *e = std::getenv("CRN_INGEST_PREWAKE_US")) g->prewake_us = std::min(100000, std::max(0, std::atoi(e)));
+  set_prewake(g);
   g->launcher = std::thread(launcher_main, g);
   (void)crn_sense_ring_count(h, +1);
   g->attached = true;
@@ -455,6 +490,7 @@ int crn_ingest_set_packet_len(crn_ingest *g, int32_t samples_per_packet) {
   g->L = samples_per_packet;
   g->P = packets_per_epoch(g->cfg, g->L);
   g->epoch_bytes = (size_t)g->P * g->L * g->sample_bytes;
+  set_prewake(g);
   return CRN_OK;
 }
 
@@ -487,6 +523,11 @@ static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, siz
     Slot &s = b.slots[sl];
     std::memcpy(b.h_iq + (size_t)sl * g->epoch_bytes + (size_t)s.npk * g->L * g->sample_bytes, iq_packet, (size_t)g->L * g->sample_bytes);
     g->packets++;
+    // a small batch is prewake_packets away from its hand-off: have the launcher awake by then (see prewake)
+    if (++b.staged == g->prewake_at && g->prewake_at > 0) {
+      g->prewake.store(true, std::memory_order_release);
+      g->cv_work.notify_one();
+    }
     if (++s.npk < g->P) return CRN_OK;
     g->open_slot[stream] = -1;
     b.complete++;

@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <map>
 #include <string>
 #include <vector>
@@ -433,6 +435,36 @@ int main() {
     REQUIRE(crn_ingest_destroy(g) == CRN_OK);
     g_fake_gpu_latency_ns = 0;
   }
+  // 12. pre-wake: ten packets before the hand-off of a small batch the pushing thread tells the launcher, which then polls for the
+  //     work instead of sleeping (bounded by $CRN_INGEST_PREWAKE_US).  Packets a radio's interval apart, epochs a sensing period
+  //     apart; the ring destroyed while the launcher is still polling for a hand-off that never comes; and switched off.
+  for (const char *us : {"600", "20000", "0"}) {
+    setenv("CRN_INGEST_PREWAKE_US", us, 1);
+    for (int B : {1, 3}) {
+      Feeder f{364};
+      REQUIRE(crn_ingest_create(&h, 1, 364, B, &g) == CRN_OK);
+      std::vector<crn_epoch_result> all;
+      for (long e = 0; e < 6; e++) {
+        for (int p = 0; p < 10; p++) {
+          std::vector<float> pk = f.packet(0, e, p);
+          REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+          std::this_thread::sleep_for(std::chrono::microseconds(28));
+          collect(g, &all);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(3));
+      }
+      REQUIRE(crn_ingest_drain(g) == CRN_OK);
+      collect(g, &all);
+      verify(all, f, 1, {6});
+      // an epoch that stays open: the launcher gives up polling after its budget; destroy never waits longer than that
+      std::vector<float> pk = f.packet(0, 6, 0);
+      REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);
+      const auto t0 = std::chrono::steady_clock::now();
+      REQUIRE(crn_ingest_destroy(g) == CRN_OK);
+      REQUIRE(std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(500));
+    }
+  }
+  unsetenv("CRN_INGEST_PREWAKE_US");
   REQUIRE(g_fake_rings_attached.load() == 0);   // every ring that attached to its handle detached again
   printf("ring_unit: ok\n");
   return 0;

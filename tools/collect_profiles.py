@@ -28,7 +28,7 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("bench_8ranks_one_gpu.json", f"{tag}_bench_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
                  ("bench_8ranks_one_gpu_scan.json", f"{tag}_bench_cfg4_eight_self_launched_ranks_one_gpu_stand_in_wire.json"),
                  ("welch_spans.txt", f"{tag}_welch_spans.txt"), ("soak.txt", f"{tag}_soak_round.txt"),
-                 ("dealt_frames_ab.txt", f"{tag}_dealt_frames_ab.txt"),
+                 ("dealt_frames_ab.txt", f"{tag}_dealt_frames_ab.txt"), ("engine_idle_gap.txt", f"{tag}_engine_idle_gap.txt"),
                  ("per_bin_error_vs_snr.txt", f"{tag}_per_bin_error_vs_snr.txt"),
                  ("engine_between_ecr_threads.txt", f"{tag}_engine_between_ecr_threads.txt")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""The engine the way a CRTS node runs it: tests/harness/ecr_threads plays the ECR's rx worker and CE worker as two threads with the
+reference's locking, packets paced at the radio's rate (364 samples / 13 Msps = 28 us), one sensing epoch per 100 ms, GPU and
+launcher thread idle in between.  Prints the engine's own counters (-s 1): kernel time and the time from the epoch's last packet to
+a readable decision — with the ring's pre-wake (the launcher thread is told ten packets ahead of the hand-off) and without it.
+
+    python3 tools/engine_idle_gap.py
+"""
+import os, subprocess, sys
+sys.path[:0] = [os.path.join(os.getcwd(), "cognitive-radio-network_amd"), os.path.join(os.getcwd(), "tests")]
+import numpy as np, crnsense as cs, signals
+cfg = cs.cfg_reference()
+L, per_seg = 364, 64
+segs = []
+for ch in range(4):
+    iq, _ = signals.make_epochs(cfg, 7, seed=900 + ch, L=L, picks=[ch] * 7)
+    segs.append(iq[: per_seg * L * 2])
+np.concatenate(segs).tofile("/tmp/iq_gap.bin")
+for name, env in (("pre-wake on (default)", {}), ("pre-wake off (CRN_INGEST_PREWAKE_US=0)", {"CRN_INGEST_PREWAKE_US": "0"}),
+                  ("pre-wake on, again", {}), ("pre-wake off, again", {"CRN_INGEST_PREWAKE_US": "0"})):
+    out = subprocess.run(["tests/harness/ecr_threads", "/tmp/iq_gap.bin", str(L), str(per_seg), "4.1", "-v", "0", "-s", "1"],
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+    n = len([ln for ln in out.stdout.splitlines() if ln.startswith("decision ")])
+    print(f"engine between the ECR's threads, packets every 28 us, one epoch per 100 ms, {name}: {n} decisions")
+    for ln in out.stdout.splitlines():
+        if ln.startswith("CE_Predictive_Node_GPU:") or ln.startswith("execute_us"):
+            print("   ", ln)

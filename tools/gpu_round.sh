@@ -40,6 +40,7 @@ timeout 120 tools/ring_rate 64 256 3 > $O/ring_rate.txt 2>&1; timeout 60 tools/r
 timeout 300 python tools/host_rate.py > $O/host_rate.txt 2>&1
 timeout 300 python tools/engine_rate.py > $O/engine_rate.txt 2>&1
 CRN_EVIDENCE_DIR=$O timeout 300 python tools/gpu_dealt_ab.py > /dev/null 2>&1
+timeout 300 python tools/engine_idle_gap.py > $O/engine_idle_gap.txt 2>&1
 timeout 300 bash tools/gpu_zeros_probe.sh > $O/zeros_probe.txt 2>&1
 timeout 300 bash tools/gpu_power_probe.sh > $O/power_probe.txt 2>&1
 timeout 300 python tools/cpu_scaling.py > $O/cpu_scaling.txt 2>&1
