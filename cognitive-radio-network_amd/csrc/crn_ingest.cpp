@@ -247,6 +247,7 @@ void launcher_main(crn_ingest *g) {
       const int i = g->work.front();
       g->work.pop_front();
       if (g->work.empty()) g->work_waiting.store(false, std::memory_order_release);
+      g->prewake.store(false, std::memory_order_release);   // the hand-off it announced is here
       lk.unlock();
       const std::string err = enqueue(g, g->batch[i]);
       lk.lock();
@@ -525,7 +526,10 @@ static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, siz
     g->packets++;
     // a small batch is prewake_packets away from its hand-off: have the launcher awake by then (see prewake)
     if (++b.staged == g->prewake_at && g->prewake_at > 0) {
-      g->prewake.store(true, std::memory_order_release);
+      {
+        std::lock_guard<std::mutex> lk(g->mu);   // (under the lock: the launcher is either waiting or will see the flag before it waits)
+        g->prewake.store(true, std::memory_order_release);
+      }
       g->cv_work.notify_one();
     }
     if (++s.npk < g->P) return CRN_OK;
