@@ -24,6 +24,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -66,6 +67,7 @@ struct Batch {
   int L = 0, P = 0;             // packet length and packets per epoch of that launch
   bool calibrating = false;     // launched while a calibration was collecting or before its thresholds were in place (launcher thread)
   std::chrono::steady_clock::time_point t_handoff;   // when the pushing thread handed it over (written before state = kQueued)
+  std::chrono::steady_clock::time_point t_dequeued, t_enqueued;   // launcher thread ($CRN_INGEST_TRACE)
   std::atomic<int> state{kFree};
 };
 
@@ -109,6 +111,11 @@ struct crn_ingest {
   int prewake_us = 600;
   int prewake_at = 0;                      // packets staged in a batch at which the launcher is told (0 = never): B P - 10, at least 1 — ten
                                            // packets before the hand-off (280 us at 13 Msps), only for batches small enough for the in-place launch
+  // $CRN_INGEST_TRACE=1: where the hand-off-to-results time goes, summed on the launcher thread and printed by crn_ingest_destroy:
+  // hand-off -> launcher has the batch (its wake-up), -> launch enqueued (the HIP calls), -> results seen (device time + noticing)
+  bool trace = false;
+  double tr_wake_us = 0, tr_enqueue_us = 0, tr_device_us = 0;
+  int64_t tr_n = 0;
   int64_t n_batches = 0, n_failed = 0, n_epochs_launched = 0, n_epochs_ready = 0;   // crn_ingest_get_stats
   double lat_us_sum = 0.0, lat_us_max = 0.0;
   // ---- noise-floor calibration (crn_ingest_calibrate): requested by the caller's thread, carried out by the launcher ----
@@ -249,7 +256,9 @@ void launcher_main(crn_ingest *g) {
       if (g->work.empty()) g->work_waiting.store(false, std::memory_order_release);
       g->prewake.store(false, std::memory_order_release);   // the hand-off it announced is here
       lk.unlock();
+      if (g->trace) g->batch[i].t_dequeued = std::chrono::steady_clock::now();
       const std::string err = enqueue(g, g->batch[i]);
+      if (g->trace) g->batch[i].t_enqueued = std::chrono::steady_clock::now();
       lk.lock();
       if (!err.empty()) {
         if (g->err_code == CRN_OK) {
@@ -303,6 +312,15 @@ void launcher_main(crn_ingest *g) {
       }
       g->lat_us_sum += us;
       if (us > g->lat_us_max) g->lat_us_max = us;
+      if (g->trace) {
+        const auto d = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+          return std::chrono::duration<double, std::micro>(b2 - a).count();
+        };
+        g->tr_wake_us += d(b.t_handoff, b.t_dequeued);
+        g->tr_enqueue_us += d(b.t_dequeued, b.t_enqueued);
+        g->tr_device_us += us - d(b.t_handoff, b.t_enqueued);
+        g->tr_n++;
+      }
       release_batch(g, b);
       inflight.pop_front();
       continue;
@@ -452,6 +470,7 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   if (const char *e = std::getenv("CRN_INGEST_ZEROCOPY_BYTES")) g->zero_copy_bytes = (size_t)std::max(0ll, std::atoll(e));
   if (const char *e = std::getenv("CRN_INGEST_PREWAKE_US")) g->prewake_us = std::min(100000, std::max(0, std::atoi(e)));
   set_prewake(g);
+  if (const char *e = std::getenv("CRN_INGEST_TRACE")) g->trace = std::atoi(e) != 0;
   g->launcher = std::thread(launcher_main, g);
   (void)crn_sense_ring_count(h, +1);
   g->attached = true;
@@ -646,6 +665,9 @@ int crn_ingest_destroy(crn_ingest *g) {
     g->cv_work.notify_all();
     g->launcher.join();  // launches what is queued, waits for what is in flight
   }
+  if (g->trace && g->tr_n > 0)
+    std::fprintf(stderr, "crn_ingest trace: %lld batches; hand-off -> launcher has it %.1f us, -> launch enqueued %.1f us, -> results seen %.1f us (means)\n",
+                 (long long)g->tr_n, g->tr_wake_us / g->tr_n, g->tr_enqueue_us / g->tr_n, g->tr_device_us / g->tr_n);
   (void)hipSetDevice(g->cfg.device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   for (int i = 0; i < 2; i++) {
