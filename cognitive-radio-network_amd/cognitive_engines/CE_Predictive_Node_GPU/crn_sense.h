@@ -248,7 +248,9 @@ CRN_API int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t wa
  * pinned buffers by the kernel itself, no copies), $CRN_INGEST_SPIN_US (150: how long after a small batch's hand-off the launcher
  * polls its event before sleeping), $CRN_INGEST_PREWAKE_US (600; 0 = off: ten packets before a small batch's hand-off the pushing
  * thread tells the launcher — one condition-variable signal, no wait — and the launcher polls for the work for at most this long
- * instead of sleeping: a sleeping thread comes back tens of microseconds late), $CRN_INGEST_TRACE (1: crn_ingest_destroy prints to
+ * instead of sleeping: a sleeping thread comes back tens of microseconds late; when the ring's stream has sat idle for more than
+ * 2 ms the launcher also queues one empty launch at that moment — the HIP calls of the first launch on an idle queue take several
+ * times longer than back to back, and this way the empty one pays for it; $CRN_INGEST_WARM_GPU=0 leaves it out), $CRN_INGEST_TRACE (1: crn_ingest_destroy prints to
  * stderr where the hand-off-to-results time went: the launcher's wake-up, the HIP calls, device time + noticing the event). */
 typedef struct crn_ingest crn_ingest;
 

@@ -379,6 +379,15 @@ int crn_sense_ring_count(crn_handle *h, int delta) {
   return CRN_OK;
 }
 
+// internal (crn_ingest.cpp): an empty launch on the ring's stream, queued at the pre-wake of a batch that follows an idle stretch —
+// the HIP calls of the first launch on a queue that sat idle for 100 ms take 20 us instead of 5 (tools/engine_idle_gap.py)
+int crn_sense_warm_stream(crn_handle *h, void *stream) {
+  if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(crn::launch_nop(static_cast<hipStream_t>(stream)));
+  return CRN_OK;
+}
+
 // internal (crn_ingest.cpp): the configuration a handle was created with
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) {
   if (!h || !out) return crn::fail(CRN_ERR_ARG, "null handle");

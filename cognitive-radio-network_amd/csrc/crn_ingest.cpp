@@ -109,6 +109,8 @@ struct crn_ingest {
   // it wakes up now and polls for the work instead of sleeping, for at most prewake_us ($CRN_INGEST_PREWAKE_US, 0 = never).
   std::atomic<bool> prewake{false};
   int prewake_us = 600;
+  bool warm_gpu = true;                    // $CRN_INGEST_WARM_GPU=0: no empty launch at the pre-wake
+  std::chrono::steady_clock::time_point t_last_launch{};   // launcher thread: when it last enqueued a batch
   int prewake_at = 0;                      // packets staged in a batch at which the launcher is told (0 = never): B P - 10, at least 1 — ten
                                            // packets before the hand-off (280 us at 13 Msps), only for batches small enough for the in-place launch
   // $CRN_INGEST_TRACE=1: where the hand-off-to-results time goes, summed on the launcher thread and printed by crn_ingest_destroy:
@@ -133,6 +135,7 @@ constexpr int kCalibMaxEpochs = 4096;      // crn_noise_floor_device uses at mos
 // defined in crn_api.cpp
 extern "C" int crn_sense_cfg_of(crn_handle *h, crn_cfg *out);
 extern "C" int crn_sense_ring_count(crn_handle *h, int delta);
+extern "C" int crn_sense_warm_stream(crn_handle *h, void *stream);
 
 namespace {
 
@@ -258,7 +261,8 @@ void launcher_main(crn_ingest *g) {
       lk.unlock();
       if (g->trace) g->batch[i].t_dequeued = std::chrono::steady_clock::now();
       const std::string err = enqueue(g, g->batch[i]);
-      if (g->trace) g->batch[i].t_enqueued = std::chrono::steady_clock::now();
+      g->t_last_launch = std::chrono::steady_clock::now();
+      if (g->trace) g->batch[i].t_enqueued = g->t_last_launch;
       lk.lock();
       if (!err.empty()) {
         if (g->err_code == CRN_OK) {
@@ -280,6 +284,8 @@ void launcher_main(crn_ingest *g) {
         lk.unlock();
         const auto t0 = std::chrono::steady_clock::now();
         const auto budget = std::chrono::microseconds(g->prewake_us);
+        // ... and the queue with it when it has sat idle: an empty launch now, well ahead of the one that matters
+        if (g->warm_gpu && t0 - g->t_last_launch > std::chrono::milliseconds(2)) (void)crn_sense_warm_stream(g->h, g->stream);
         while (!g->work_waiting.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - t0 < budget) cpu_relax();
         lk.lock();
         continue;
@@ -471,6 +477,7 @@ static int ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_p
   if (const char *e = std::getenv("CRN_INGEST_PREWAKE_US")) g->prewake_us = std::min(100000, std::max(0, std::atoi(e)));
   set_prewake(g);
   if (const char *e = std::getenv("CRN_INGEST_TRACE")) g->trace = std::atoi(e) != 0;
+  if (const char *e = std::getenv("CRN_INGEST_WARM_GPU")) g->warm_gpu = std::atoi(e) != 0;
   g->launcher = std::thread(launcher_main, g);
   (void)crn_sense_ring_count(h, +1);
   g->attached = true;

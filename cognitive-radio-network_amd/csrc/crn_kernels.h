@@ -121,6 +121,7 @@ hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *sc
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
 hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream);
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
+hipError_t launch_nop(hipStream_t stream);   // one empty workgroup (crn_sense_warm_stream)
 
 }  // namespace crn
 #endif

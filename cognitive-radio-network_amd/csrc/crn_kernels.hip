@@ -523,6 +523,12 @@ __global__ __launch_bounds__(256) void pack_sc16_kernel(const float2 *iq, long l
   }
 }
 
+__global__ void nop_kernel() {}
+hipError_t launch_nop(hipStream_t stream) {
+  hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, stream);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream) {
   if (n_samples <= 0) return hipSuccess;
   long long blocks = (n_samples + 255) / 256;

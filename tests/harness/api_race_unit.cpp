@@ -42,6 +42,7 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipS
   return hipSuccess;
 }
 int sense_num_variants() { return 24; }
+hipError_t launch_nop(hipStream_t) { return hipSuccess; }
 int sense_deal_rounds(int, bool, int) { return 0; }
 unsigned sense_ref_acc_mask(int) { return 0xFFFFu; }
 bool sense_variant_available(int v) { return v == 0; }

@@ -61,6 +61,7 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
   return hipSuccess;
 }
 int sense_num_variants() { return 24; }
+hipError_t launch_nop(hipStream_t) { return hipSuccess; }
 // (the rule of csrc/crn_kernels.hip restated: frames of 512 / 1024 points, K >= 2, the frame slots within 160 KiB of LDS)
 int sense_deal_rounds(int fft_len, bool mag, int K) {
   if ((fft_len != 512 && fft_len != 1024) || K < 2) return 0;

@@ -31,6 +31,8 @@ struct crn_handle { crn_cfg cfg; };
 int crn_sense_cfg_of(crn_handle *h, crn_cfg *out) { *out = h->cfg; return CRN_OK; }
 static std::atomic<int> g_fake_rings_attached{0};
 int crn_sense_ring_count(crn_handle *, int delta) { g_fake_rings_attached += delta; return CRN_OK; }
+static std::atomic<long> g_fake_warm_launches{0};
+int crn_sense_warm_stream(crn_handle *, void *) { g_fake_warm_launches++; return CRN_OK; }
 // calibration (crn_ingest_calibrate -> the ring's launcher thread -> these two): "the median band energy" of the stand-in's features
 // is the mean of features[1] (the epochs' first samples: what the test put there).  The stand-in makes the kinds of HIP call the
 // real one makes — an upload, a wait — through the fake runtime, so a test that watches a thread sees them if they run on it.

@@ -441,6 +441,7 @@ int main() {
   for (const char *us : {"600", "20000", "0"}) {
     setenv("CRN_INGEST_PREWAKE_US", us, 1);
     for (int B : {1, 3}) {
+      const long warm_before = g_fake_warm_launches.load();
       Feeder f{364};
       REQUIRE(crn_ingest_create(&h, 1, 364, B, &g) == CRN_OK);
       std::vector<crn_epoch_result> all;
@@ -456,6 +457,9 @@ int main() {
       REQUIRE(crn_ingest_drain(g) == CRN_OK);
       collect(g, &all);
       verify(all, f, 1, {6});
+      // a pre-wake that follows an idle stretch (> 2 ms since the last launch) also queues one empty launch on the ring's stream
+      const long warm = g_fake_warm_launches.load() - warm_before;
+      REQUIRE(atoi(us) == 0 ? warm == 0 : (warm >= 1 && warm <= 6));
       // an epoch that stays open: the launcher gives up polling after its budget; destroy never waits longer than that
       std::vector<float> pk = f.packet(0, 6, 0);
       REQUIRE(crn_ingest_push(g, 0, pk.data()) == CRN_OK);

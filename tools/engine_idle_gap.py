@@ -16,12 +16,17 @@ for ch in range(4):
     iq, _ = signals.make_epochs(cfg, 7, seed=900 + ch, L=L, picks=[ch] * 7)
     segs.append(iq[: per_seg * L * 2])
 np.concatenate(segs).tofile("/tmp/iq_gap.bin")
-for name, env in (("pre-wake on (default)", {}), ("pre-wake off (CRN_INGEST_PREWAKE_US=0)", {"CRN_INGEST_PREWAKE_US": "0"}),
-                  ("pre-wake on, again", {}), ("pre-wake off, again", {"CRN_INGEST_PREWAKE_US": "0"})):
+for name, env in (("pre-wake on (default)", {}), ("pre-wake without the empty warm-up launch (CRN_INGEST_WARM_GPU=0)", {"CRN_INGEST_WARM_GPU": "0"}),
+                  ("pre-wake off (CRN_INGEST_PREWAKE_US=0)", {"CRN_INGEST_PREWAKE_US": "0"}),
+                  ("pre-wake on, again", {}), ("pre-wake without the empty warm-up launch, again", {"CRN_INGEST_WARM_GPU": "0"}),
+                  ("pre-wake off, again", {"CRN_INGEST_PREWAKE_US": "0"})):
     out = subprocess.run(["tests/harness/ecr_threads", "/tmp/iq_gap.bin", str(L), str(per_seg), "4.1", "-v", "0", "-s", "1"],
-                         capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, CRN_INGEST_TRACE="1", **env))
     n = len([ln for ln in out.stdout.splitlines() if ln.startswith("decision ")])
     print(f"engine between the ECR's threads, packets every 28 us, one epoch per 100 ms, {name}: {n} decisions")
     for ln in out.stdout.splitlines():
         if ln.startswith("CE_Predictive_Node_GPU:") or ln.startswith("execute_us"):
+            print("   ", ln)
+    for ln in out.stderr.splitlines():
+        if ln.startswith("crn_ingest trace"):
             print("   ", ln)
