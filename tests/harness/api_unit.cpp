@@ -346,6 +346,11 @@ static void test_arguments_and_counters() {
   REQUIRE(crn_sense_set_variant(h, 7) == CRN_ERR_ARG && std::strstr(crn_last_error(), "measurement variant") != nullptr);
   REQUIRE(crn_sense_set_variant(h, 23) == CRN_OK && crn_sense_set_variant(h, 0) == CRN_OK);
   REQUIRE(crn_sense_set_variant(h, 403) == CRN_ERR_ARG && crn_sense_set_variant(h, -1) == CRN_ERR_ARG);
+  {
+    int64_t n = -1;
+    REQUIRE(crn_sense_dealt_launches(nullptr, &n) == CRN_ERR_ARG && crn_sense_dealt_launches(h, nullptr) == CRN_ERR_ARG);
+    REQUIRE(crn_sense_dealt_launches(h, &n) == CRN_OK && n >= 0);
+  }
   // live updates reach the next launch's tables
   float thr[4] = {9.f, 8.f, 7.f, 6.f};
   REQUIRE(crn_sense_set_thresholds(h, thr, 4, nullptr) == CRN_OK);
