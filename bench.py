@@ -230,8 +230,11 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if args.variant not in (0, 2, 13, 23) and args.variant < 100:
+    if args.variant not in (0, 2, 13) and args.variant < 100:
         os.environ["CRN_SENSE_AB"] = "1"   # measurement variants live in libcrnsense_ab.so, not in the shipped library
+    if args.wire_format and "CRN_SENSE_LIB" not in os.environ:
+        # the wire-format kernels are optional: libcrnsense_sc16.so (make -C csrc SC16=1), not the shipped library
+        os.environ["CRN_SENSE_LIB"] = os.path.join(ROOT, "cognitive-radio-network_amd", "libcrnsense_sc16.so")
     import crnsense as cs
     from sharding import make_device_exchange, shard
 
@@ -295,6 +298,8 @@ def main():
     info = sensor.kernel_info()
     if os.environ.get("CRN_SENSE_AB") == "1":
         workload += " [A/B BUILD libcrnsense_ab.so: measurement variant, not the shipped library]"
+    elif os.path.basename(cs.LIB_PATH) != "libcrnsense.so":
+        workload += f" [LIBRARY {os.path.basename(cs.LIB_PATH)}, not the shipped libcrnsense.so]"
     pruned = "PASS3_ROWS" in info["name"]
     if pruned:
         n_kept = info["name"].split("PASS3_ROWS=")[1].split("-of-16")[0]

@@ -204,24 +204,6 @@ CRN_API int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epo
                          int32_t samples_per_frame, int64_t epoch_stride,
                          const crn_out *d_out, void *stream);
 
-/* crn_sense_run_device on samples kept in the radio's WIRE FORMAT: two int16 per complex sample (re, im; full scale 32768), 4 bytes
- * instead of 8 — what the reference's USRPs put on the network (src/extensible_cognitive_radio.cpp:1263-1265: 363-364 samples per
- * 1500-byte packet) and UHD's recv converts to the complex floats of ce_usrp_rx_buffer (:1071-1072).  The kernel converts in its
- * first pass (int16 / 32768, exact in fp32), so every output is bit-identical to crn_sense_run_device on the converted floats,
- * while HBM holds and streams half the bytes.  Same arguments otherwise (strides in samples; d_iq 4-byte aligned); every configuration
- * the float entry point takes. */
-CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
-                                      int64_t epoch_stride, const crn_out *d_out, void *stream);
-/* The constant of the int16 -> float conversion that wire-format launches stand for: a sample is k / full_scale.  32768 (the
- * default) is a power of two, applied once per epoch and exact — that is what makes the outputs bit-identical to the float path.
- * A converter with another constant (UHD's sc16 -> fc32 scales by 1/32767) is matched by naming it here: magnitudes then carry
- * 1/full_scale and energies its square, and the outputs equal the float path's on floats converted with that constant to within
- * rounding (~1e-7 relative) instead of bit for bit. */
-CRN_API int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale);
-/* Complex floats -> wire format on the device: round(x * full_scale) (the handle's: 32768 unless crn_sense_set_wire_full_scale
- * changed it), clipped to int16; n_samples complex samples. */
-CRN_API int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream);
-
 /* Host-buffer convenience used by the engine wrapper: H2D, run, D2H, synchronise. */
 CRN_API int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs,
                        int32_t samples_per_frame, int64_t epoch_stride, const crn_out *out);
@@ -278,12 +260,6 @@ typedef struct crn_epoch_result {
  * ring will ever use is allocated by this call. */
 CRN_API int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet,
                               int32_t epochs_per_batch, crn_ingest **out);
-/* The same ring for packets in the radio's wire format (int16 pairs, 4 bytes per complex sample: crn_sense_run_device_sc16): half
- * the bytes through the pushing thread's copy, the bus and HBM.  Packets go in through crn_ingest_push_sc16 (CRN_ERR_STATE for the
- * other kind of push); everything else is shared. */
-CRN_API int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
-                                   crn_ingest **out);
-CRN_API int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet);
 /* Threshold plans whose thresholds are lambda x a measured noise floor (the scan engine's start-up): the next
  * n_epochs epochs that come back only feed the estimate — crn_noise_floor_device's median of medians over their features — and with
  * the last of them the ring's launcher thread uploads them, reduces them and puts lambda x the estimate in as every band's
@@ -525,7 +501,10 @@ CRN_API int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, flo
 CRN_API int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream);
 /* Replace the per-band thresholds of a handle (cfg.thresh; CRN_DECIDE_THRESHOLD): ordered on `stream` — launches enqueued on it
  * after the call see the new values, launches before it the old ones.  `thresh` is read before the call returns (it is staged in
- * pinned memory of the handle's own, one slot per update: the asynchronous copy never reads memory a later call rewrites). */
+ * pinned memory of the handle's own, one slot per update: the asynchronous copy never reads memory a later call rewrites).
+ * Updates (this call, crn_sense_set_ann, crn_sense_calibrate_thresholds) cannot be captured into a hipGraph — a replay would upload
+ * whatever the reused staging slot holds by then: on a stream that is capturing they return CRN_ERR_STATE and enqueue nothing.
+ * Launches capture fine. */
 CRN_API int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream);
 
 /* Allocate, now, what crn_noise_floor_host and crn_sense_calibrate_thresholds need (pinned + device upload buffers for 4096 epochs
@@ -589,10 +568,41 @@ CRN_API int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, i
  * results: 0 (= 13) the default; 2 without the pruning of pass 3 to the registers the reference channel plan reaches (what any band
  * table outside that plan runs anyway); 23 every twiddle in registers at three workgroups per CU.  100 + n / 200 + n / 300 + n
  * override the launch geometry (epochs per big workgroup; x 256 epochs in tail workgroups; epochs per tail workgroup) and change
- * no result.  Everything else — other
- * schedules, ablations that compute nothing useful, a trace build — is a measurement variant compiled only into libcrnsense_ab.so
- * (make -C csrc ab) and refused here with CRN_ERR_ARG. */
+ * no result.  The measurement forms (7, 17, 19-22, 26, 27: the same flags in other combinations, and a build with in-kernel time
+ * stamps) are compiled only into libcrnsense_ab.so (make -C csrc ab) and refused here with CRN_ERR_ARG; every other number is refused
+ * by both. */
 CRN_API int crn_sense_set_variant(crn_handle *h, int32_t variant);
+
+/* -- optional: wire-format input --------------------------------------------------------------
+ * NOT in the default library.  `make -C csrc SC16=1` builds libcrnsense_sc16.so — libcrnsense.so plus the wire-format kernels and the
+ * five entry points below; a program that uses them defines CRN_WITH_SC16 before including this header and links that library.
+ * (BASELINE.json's north star reads complex floats; this halves the bytes for callers that hold the radio's int16 samples.) */
+#ifdef CRN_WITH_SC16
+/* crn_sense_run_device on samples kept in the radio's WIRE FORMAT: two int16 per complex sample (re, im; full scale 32768), 4 bytes
+ * instead of 8 — what the reference's USRPs put on the network (src/extensible_cognitive_radio.cpp:1263-1265: 363-364 samples per
+ * 1500-byte packet) and UHD's recv converts to the complex floats of ce_usrp_rx_buffer (:1071-1072).  The kernel converts in its
+ * first pass (int16 / 32768, exact in fp32), so every output is bit-identical to crn_sense_run_device on the converted floats,
+ * while HBM holds and streams half the bytes.  Same arguments otherwise (strides in samples; d_iq 4-byte aligned); every configuration
+ * the float entry point takes. */
+CRN_API int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
+                                      int64_t epoch_stride, const crn_out *d_out, void *stream);
+/* The constant of the int16 -> float conversion that wire-format launches stand for: a sample is k / full_scale.  32768 (the
+ * default) is a power of two, applied once per epoch and exact — that is what makes the outputs bit-identical to the float path.
+ * A converter with another constant (UHD's sc16 -> fc32 scales by 1/32767) is matched by naming it here: magnitudes then carry
+ * 1/full_scale and energies its square, and the outputs equal the float path's on floats converted with that constant to within
+ * rounding (~1e-7 relative) instead of bit for bit. */
+CRN_API int crn_sense_set_wire_full_scale(crn_handle *h, double full_scale);
+/* Complex floats -> wire format on the device: round(x * full_scale) (the handle's: 32768 unless crn_sense_set_wire_full_scale
+ * changed it), clipped to int16; n_samples complex samples. */
+CRN_API int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, int16_t *d_out, void *stream);
+
+/* The same ring for packets in the radio's wire format (int16 pairs, 4 bytes per complex sample: crn_sense_run_device_sc16): half
+ * the bytes through the pushing thread's copy, the bus and HBM.  Packets go in through crn_ingest_push_sc16 (CRN_ERR_STATE for the
+ * other kind of push); everything else is shared. */
+CRN_API int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch,
+                                   crn_ingest **out);
+CRN_API int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet);
+#endif /* CRN_WITH_SC16 */
 
 CRN_API const char *crn_last_error(void);
 CRN_API int crn_abi_version(void);

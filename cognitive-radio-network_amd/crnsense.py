@@ -7,11 +7,15 @@ visible.
 """
 import ctypes as C
 import os
+import weakref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# env overrides: CRN_SENSE_LIB = another build of the library; CRN_SENSE_AB=1 = libcrnsense_ab.so, the build that also carries the
+# env overrides: CRN_SENSE_LIB = another build of the library (libcrnsense_sc16.so: the optional wire-format kernels, make SC16=1;
+# libcrnsense_plain.so: no assembly filter, a test artefact); CRN_SENSE_AB=1 = libcrnsense_ab.so, the build that also carries the
 # measurement variants (tools/, the A/B test) — the engine and bench.py's default run use the shipped library
 LIB_PATH = os.environ.get("CRN_SENSE_LIB") or os.path.join(HERE, "libcrnsense_ab.so" if os.environ.get("CRN_SENSE_AB") == "1" else "libcrnsense.so")
+SC16_LIB_PATH = os.path.join(HERE, "libcrnsense_sc16.so")
+PLAIN_LIB_PATH = os.path.join(HERE, "libcrnsense_plain.so")
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
 CRN_ABI_VERSION = 3
@@ -24,15 +28,17 @@ MODE_REF_MAG, MODE_ENERGY = 0, 1
 DECIDE_ANN, DECIDE_THRESHOLD, DECIDE_NONE = 0, 1, 2
 WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 
-# every symbol include/crn_sense.h declares (tests check the library exports them all)
+# the optional wire-format entry points (include/crn_sense.h, #ifdef CRN_WITH_SC16): only in a library built with make SC16=1
+SC16_EXPORTS = ["crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale", "crn_ingest_create_sc16", "crn_ingest_push_sc16"]
+
+# every symbol include/crn_sense.h declares unconditionally (tests check the library exports them all)
 EXPORTS = [
     "crn_cfg_reference", "crn_cfg_energy_scaled", "crn_cfg_welch", "crn_cfg_reference_scaled", "crn_cfg_welch_scaled",
     "crn_cfg_save_ann", "crn_cfg_load_ann", "crn_sense_set_ann", "crn_sense_set_bands", "crn_noise_floor_host", "crn_sense_synchronize",
     "crn_sense_create", "crn_sense_destroy", "crn_sense_run_device", "crn_sense_run_host",
-    "crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale",
     "crn_synth_fill_device", "crn_synth_fill_device_ex", "crn_ann_train_device", "crn_fft_forward_device",
     "crn_sense_kernel_info", "crn_sense_set_variant", "crn_sense_dealt_launches",
-    "crn_ingest_create", "crn_ingest_push", "crn_ingest_create_sc16", "crn_ingest_push_sc16", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
+    "crn_ingest_create", "crn_ingest_push", "crn_ingest_flush", "crn_ingest_poll", "crn_ingest_drain",
     "crn_ingest_destroy", "crn_ingest_set_packet_len", "crn_ingest_wait", "crn_ingest_dropped", "crn_ingest_packets_per_epoch",
     "crn_noise_floor_device", "crn_sense_set_thresholds", "crn_sense_reserve_noise_floor", "crn_sense_calibrate_thresholds",
     "crn_ingest_calibrate", "crn_ingest_noise_floor",
@@ -151,10 +157,13 @@ def lib():
         L.crn_sense_destroy.argtypes = [C.c_void_p]
         L.crn_sense_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                            C.POINTER(Out), C.c_void_p]
-        L.crn_sense_run_device_sc16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
-                                                C.POINTER(Out), C.c_void_p]
-        L.crn_sense_set_wire_full_scale.argtypes = [C.c_void_p, C.c_double]
-        L.crn_pack_sc16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        if hasattr(L, "crn_sense_run_device_sc16"):   # a library built with make SC16=1
+            L.crn_sense_run_device_sc16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                                    C.POINTER(Out), C.c_void_p]
+            L.crn_sense_set_wire_full_scale.argtypes = [C.c_void_p, C.c_double]
+            L.crn_pack_sc16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+            L.crn_ingest_create_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+            L.crn_ingest_push_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.crn_sense_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                          C.POINTER(Out)]
         L.crn_synth_fill_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
@@ -170,8 +179,6 @@ def lib():
         L.crn_sense_set_variant.argtypes = [C.c_void_p, C.c_int32]
         L.crn_ingest_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.crn_ingest_push.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-        L.crn_ingest_create_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
-        L.crn_ingest_push_sc16.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.crn_ingest_flush.argtypes = [C.c_void_p]
         L.crn_ingest_poll.argtypes = [C.c_void_p, C.POINTER(EpochResult), C.c_int32, C.POINTER(C.c_int32)]
         L.crn_ingest_drain.argtypes = [C.c_void_p]
@@ -206,6 +213,17 @@ def lib():
         L.crn_comm_info.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
         _lib = L
     return _lib
+
+
+def has_sc16():
+    """Does the loaded library carry the optional wire-format kernels and entry points (a `make SC16=1` build)?"""
+    return hasattr(lib(), "crn_sense_run_device_sc16")
+
+
+def _need_sc16(what):
+    if not has_sc16():
+        raise CrnError(f"{what}: {LIB_PATH} was built without the optional wire-format kernels "
+                       "(make -C csrc SC16=1 builds libcrnsense_sc16.so; select it with $CRN_SENSE_LIB)")
 
 
 def build_info():
@@ -278,7 +296,9 @@ class Sensor:
     def __init__(self, cfg):
         self.cfg = cfg
         self._h = C.c_void_p()
-        self._rings = []      # Ingest objects attached to this handle: closed before it (crn_sense_destroy refuses otherwise)
+        # Ingest objects attached to this handle: closed before it (crn_sense_destroy refuses otherwise).  Weak references: a ring keeps
+        # its sensor alive, not the other way round, so a dropped Ingest is destroyed by its refcount (launcher thread, pinned buffers)
+        self._rings = weakref.WeakSet()
         check(lib().crn_sense_create(C.byref(cfg), C.byref(self._h)), "crn_sense_create")
 
     def close(self):
@@ -382,15 +402,19 @@ class Sensor:
         """iq_ptr / out_ptrs: raw device addresses (ints); out_ptrs keys are Out fields.  sc16: iq_ptr holds the radio's wire
         format (int16 pairs, 4 bytes per complex sample)."""
         o = Out(**{k: (v or None) for k, v in out_ptrs.items()})
+        if sc16:
+            _need_sc16("run_device(sc16=True)")
         fn = lib().crn_sense_run_device_sc16 if sc16 else lib().crn_sense_run_device
         check(fn(self._h, iq_ptr, n_epochs, L, epoch_stride, C.byref(o), C.c_void_p(stream or None)),
               "crn_sense_run_device_sc16" if sc16 else "crn_sense_run_device")
 
     def set_wire_full_scale(self, full_scale):
+        _need_sc16("set_wire_full_scale")
         check(lib().crn_sense_set_wire_full_scale(self._h, float(full_scale)), "crn_sense_set_wire_full_scale")
 
     def pack_sc16_device(self, iq_ptr, n_samples, out_ptr, stream=0):
         """complex floats -> int16 pairs on the device (n_samples complex samples)."""
+        _need_sc16("pack_sc16_device")
         check(lib().crn_pack_sc16_device(self._h, iq_ptr, n_samples, out_ptr, C.c_void_p(stream or None)), "crn_pack_sc16_device")
 
     def run_host(self, iq, n_epochs, L=None, want_spectrum=False, epoch_stride=0):
@@ -541,10 +565,12 @@ class Ingest:
         """sc16: packets are int16 pairs (the radio's wire format) instead of complex floats."""
         self.sensor = sensor
         self._g = C.c_void_p()
+        if sc16:
+            _need_sc16("Ingest(sc16=True)")
         self._push = lib().crn_ingest_push_sc16 if sc16 else lib().crn_ingest_push
         create = lib().crn_ingest_create_sc16 if sc16 else lib().crn_ingest_create
         check(create(sensor._h, n_streams, samples_per_packet, epochs_per_batch, C.byref(self._g)), "crn_ingest_create")
-        sensor._rings.append(self)
+        sensor._rings.add(self)
 
     def calibrate(self, n_epochs, lam):
         """Post a noise-floor calibration over the next n_epochs epochs (carried out by the ring's launcher thread)."""
@@ -602,5 +628,10 @@ class Ingest:
         if self._g:
             lib().crn_ingest_destroy(self._g)
             self._g = C.c_void_p()
-            if self in self.sensor._rings:
-                self.sensor._rings.remove(self)
+            self.sensor._rings.discard(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -30,6 +30,10 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 struct crn_handle {
+  explicit crn_handle(int dev) : device(dev) {}
+  // The HIP device, fixed at creation: what every entry point makes current, readable without a lock (cfg.device is the same number,
+  // but cfg as a whole is rewritten under tables_mu by crn_sense_set_bands while an ingest ring's launcher thread may be in here).
+  const int device;
   crn_cfg cfg;
   int variant = 0;
   int groups_per_wg = 0;        // 0 = automatic
@@ -40,7 +44,8 @@ struct crn_handle {
   int n_row_entries = 0;        // > 0: the band plan qualifies for register-resident band sums
   int aligned_shift = 0;        // N = 4096, equal contiguous bands of 64 / 128 / 256 bins in order: log2 of the width
   std::atomic<int> n_rings{0};  // ingest rings created on this handle (they size their result buffers for cfg.n_bands)
-  int n_cus = 256;              // compute units of cfg.device (workgroup slots = n_cus x workgroups per CU): read at creation
+  int n_cus = 256;              // compute units of the device (workgroup slots = n_cus x workgroups per CU): read at creation
+  size_t lds_budget = 64 * 1024;   // LDS a workgroup may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock: 160 KiB on gfx950)
   unsigned acc_mask = 0xFFFFu;  // accumulator registers (bit j R3 + d) that hold a bin of some band (N = 4096: the 256-bin rows)
   // one device slab holding every table
   void *d_tables = nullptr;
@@ -65,6 +70,10 @@ struct crn_handle {
   // first write until its copies are enqueued (set_bands: until the old slab is freed) — so a launch sees one plan, whole, and no
   // launch can pick up a slab after the update that frees it has started.
   std::mutex tables_mu;
+  // The noise-floor scratch and upload buffers (d_nf_scratch, h_nf_features, d_nf_features) and the blocking reductions that use them:
+  // a lock of their own, so that a calibration waiting for the device never holds tables_mu — launches on other threads go on.
+  // Order: nf_mu before tables_mu.
+  std::mutex nf_mu;
   // Pinned staging of the small asynchronous updates (thresholds, weights): hipMemcpyAsync reads its source when the stream gets
   // there, so each update copies from a slot of its own that is not rewritten until the event behind its copies has completed.
   struct UpdateSlot {
@@ -326,12 +335,13 @@ int crn_sense_create(const crn_cfg *cfg, crn_handle **out) {
   if (cfg->device < 0 || cfg->device >= ndev) return crn::fail(CRN_ERR_ARG, "cfg.device out of range");
   HIP_TRY(hipSetDevice(cfg->device));
 
-  crn_handle *h = new (std::nothrow) crn_handle();
+  crn_handle *h = new (std::nothrow) crn_handle(cfg->device);
   if (!h) return crn::fail(CRN_ERR_NOMEM, "out of host memory");
   h->cfg = *cfg;
   {
-    int cus = 0;
+    int cus = 0, lds = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_cus = cus;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) h->lds_budget = (size_t)lds;
   }
   if (int rc = build_tables(h)) {
     delete h;
@@ -353,7 +363,7 @@ int crn_sense_destroy(crn_handle *h) {
   if (h->n_rings.load(std::memory_order_acquire) > 0)
     return crn::fail(CRN_ERR_STATE, "crn_sense_destroy: " + std::to_string(h->n_rings.load()) + " ingest ring(s) are still attached to this "
                                     "handle (crn_ingest_destroy them first)");
-  (void)hipSetDevice(h->cfg.device);
+  (void)hipSetDevice(h->device);
   if (h->upd) (void)hipHostFree(h->upd);
   for (int i = 0; i < crn_handle::kUpdateSlots; i++)
     if (h->upd_done[i]) (void)hipEventDestroy(h->upd_done[i]);
@@ -383,7 +393,7 @@ int crn_sense_ring_count(crn_handle *h, int delta) {
 // the HIP calls of the first launch on a queue that sat idle for 100 ms take 20 us instead of 5 (tools/engine_idle_gap.py)
 int crn_sense_warm_stream(crn_handle *h, void *stream) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));   // (the launcher thread, at every pre-wake: no lock, nothing of cfg)
   HIP_TRY(crn::launch_nop(static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }
@@ -423,8 +433,9 @@ int crn_sense_set_variant(crn_handle *h, int32_t variant) {
   }
   if (variant < 0 || variant > crn::sense_num_variants()) return crn::fail(CRN_ERR_ARG, "variant out of range");
   if (!crn::sense_variant_available(variant))
-    return crn::fail(CRN_ERR_ARG, "variant " + std::to_string(variant) + " is a measurement variant: it is compiled into libcrnsense_ab.so "
-                                  "(make -C csrc ab), not into the shipped library");
+    return crn::fail(CRN_ERR_ARG, "variant " + std::to_string(variant) + " is not a form of this library: the measurement variants (7, 17, 19-22, 26, 27) "
+                                  "are compiled into libcrnsense_ab.so (make -C csrc ab), not into the shipped library; any other number names "
+                                  "a form that no longer exists");
   h->variant = variant;
   return CRN_OK;
 }
@@ -445,16 +456,16 @@ int crn_sense_kernel_info(crn_handle *h, char *name, int32_t name_len, int32_t *
     const bool plain4096 = h->cfg.fft_len == 4096 && h->cfg.mode != CRN_MODE_REF_MAG && h->cfg.window == CRN_WINDOW_RECT;
     // what a launch without a spectrum output runs (a spectrum request falls back to full rows / the LDS close)
     bool reg_close = h->n_row_entries > 0 && h->cfg.window == CRN_WINDOW_RECT;
-    if (plain4096) {  // of the A/B set only these carry the register form
+    if (plain4096) {  // the forms of the plain kernel that carry the register close
       const int v = h->variant == 0 ? 13 : h->variant;
       const bool rows_ok = (h->acc_mask & ~0x8267u) == 0;
-      reg_close = reg_close && (v == 2 || v == 13 || v == 23 || v == 16 || v == 17 || v == 18 || (v == 7 && rows_ok));
+      reg_close = reg_close && (v == 2 || v == 13 || v == 17 || (v == 7 && rows_ok));
     }
     // pass 3 / accumulate pruned to the reference channel plan's registers: the plain 4096-point kernel's default form, and the
     // register-close kernels of every other size and mode (what a launch without a spectrum output runs)
     const unsigned ref_mask = crn::sense_ref_acc_mask(h->cfg.fft_len);
     const bool inside = (h->acc_mask & ~ref_mask) == 0 && ref_mask != 0xFFFFu && h->variant != 2;
-    const bool pruned = reg_close && inside && h->cfg.window == CRN_WINDOW_RECT && (!plain4096 || h->variant == 0 || h->variant == 13 || h->variant == 23);
+    const bool pruned = reg_close && inside && h->cfg.window == CRN_WINDOW_RECT && (!plain4096 || h->variant == 0 || h->variant == 13);
     // periodic Hann in energy mode: the window is folded into pass 1 (whole frames); with the Welch scan's plan
     // (N = 4096, equal contiguous bands) the close forms band sums by DPP
     const bool hann_fold = h->cfg.window == CRN_WINDOW_HANN && h->cfg.mode != CRN_MODE_REF_MAG;
@@ -511,7 +522,7 @@ int crn_sense_set_timing(crn_handle *h, int32_t on) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->timing_mu);
   if (on && !h->t_start[0]) {
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipSetDevice(h->device));
     for (int i = 0; i < crn_handle::kTimedSlots; i++) {
       HIP_TRY(hipEventCreate(&h->t_start[i]));
       HIP_TRY(hipEventCreate(&h->t_stop[i]));
@@ -550,7 +561,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   if (n_epochs > (int64_t)0x7fffffff) return crn::fail(CRN_ERR_ARG, "n_epochs too large for one launch");
-  HIP_TRY(hipSetDevice(h->cfg.device));  // a NULL stream / a launch follows the calling thread's current device
+  HIP_TRY(hipSetDevice(h->device));  // a NULL stream / a launch follows the calling thread's current device
   // a workgroup addresses its window with 32-bit byte offsets
   if ((64 * epoch_stride + (int64_t)(h->cfg.frames_per_epoch + 1) * frame_stride + 2 * (int64_t)h->cfg.fft_len) * sample_bytes >= ((int64_t)1 << 31))
     return crn::fail(CRN_ERR_ARG, "epoch_stride too large (a workgroup window must stay below 2 GiB)");
@@ -605,7 +616,8 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // workgroups per CU — the energy forms lose (17.5 -> 20.5), so the switch sits at one per CU.
     const int64_t deal_max = h->deal_max_epochs >= 0 ? h->deal_max_epochs : (int64_t)h->n_cus;
     if (n_epochs <= deal_max && (h->variant == 0 || h->variant == 13))
-      p.deal_rounds = crn::sense_deal_rounds(c.fft_len, c.mode == CRN_MODE_REF_MAG, c.frames_per_epoch);
+      p.deal_rounds = crn::sense_deal_rounds(c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT,
+                                             c.window == CRN_WINDOW_HANN && samples_per_frame == c.fft_len, c.frames_per_epoch, h->lds_budget);
   }
   p.tw1 = h->d_tw1;
   p.tw2 = h->d_tw2;
@@ -630,11 +642,8 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   }
   p.n_row_entries = h->n_row_entries;
   p.features = d_out->features;
-#ifdef CRN_AB_VARIANTS
-  p.ann_out = (c.decide == CRN_DECIDE_ANN || h->variant == 17) ? d_out->ann_out : nullptr;  // 17: the trace build's stamps go there
-#else
-  p.ann_out = c.decide == CRN_DECIDE_ANN ? d_out->ann_out : nullptr;
-#endif
+  // (a measurement form that writes time stamps puts them there: libcrnsense_ab.so only)
+  p.ann_out = (c.decide == CRN_DECIDE_ANN || crn::sense_variant_traces(h->variant)) ? d_out->ann_out : nullptr;
   p.decision = d_out->decision;
   p.occupancy = d_out->occupancy;
   p.spectrum = d_out->spectrum;
@@ -650,6 +659,8 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   const hipError_t le = crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT, h->variant,
                                           static_cast<hipStream_t>(stream), sc16);
   if (slot >= 0) (void)hipEventRecord(h->t_stop[slot], static_cast<hipStream_t>(stream));   // also after a failed launch: the slot must complete
+  if (le == hipErrorNotSupported && sc16)
+    return crn::fail(CRN_ERR_ARG, "this library was built without the wire-format kernels (make -C csrc SC16=1 builds libcrnsense_sc16.so)");
   if (le != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("launch_sense: ") + hipGetErrorString(le));
   // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
   const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
@@ -665,6 +676,14 @@ int crn_sense_run_device(crn_handle *h, const float *d_iq, int64_t n_epochs, int
   return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, false);
 }
 
+// internal (crn_ingest.cpp): either sample format through one call — a ring of wire-format packets (bytes_per_sample 4) exists only
+// in a library built with the wire-format kernels
+int crn_sense_run_device_any(crn_handle *h, const void *d_iq, int32_t bytes_per_sample, int64_t n_epochs, int32_t samples_per_frame,
+                             int64_t epoch_stride, const crn_out *d_out, void *stream) {
+  return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, bytes_per_sample == 4);
+}
+
+#ifdef CRN_WITH_SC16   // optional: wire-format input (make SC16=1 -> libcrnsense_sc16.so; include/crn_sense.h)
 int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                               int64_t epoch_stride, const crn_out *d_out, void *stream) {
   return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, true);
@@ -682,10 +701,11 @@ int crn_pack_sc16_device(crn_handle *h, const float *d_iq, int64_t n_samples, in
   if (!h || !d_iq || !d_out) return crn::fail(CRN_ERR_ARG, "null handle / buffer");
   if (n_samples < 0) return crn::fail(CRN_ERR_ARG, "n_samples < 0");
   std::lock_guard<std::mutex> lk(h->tables_mu);
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(crn::launch_pack_sc16(d_iq, n_samples, d_out, (float)h->wire_full_scale, static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }
+#endif  // CRN_WITH_SC16
 
 int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t samples_per_frame,
                        int64_t epoch_stride, const crn_out *out) {
@@ -696,7 +716,7 @@ int crn_sense_run_host(crn_handle *h, const float *iq, int64_t n_epochs, int32_t
   int frame_stride = 0;
   if (int rc = resolve_strides(h, samples_per_frame, &epoch_stride, &frame_stride)) return rc;
   const crn_cfg &c = h->cfg;
-  HIP_TRY(hipSetDevice(c.device));
+  HIP_TRY(hipSetDevice(h->device));
   // samples touched: last epoch start + (K-1) frame strides + the last frame
   const int64_t last_frame = c.hop == c.fft_len ? samples_per_frame : c.fft_len;
   const size_t n_samples = (size_t)((n_epochs - 1) * epoch_stride + (int64_t)(c.frames_per_epoch - 1) * frame_stride + last_frame);
@@ -793,27 +813,59 @@ int crn_sense_reserve_host(crn_handle *h, int64_t max_epochs, int32_t want_spect
 }
 
 namespace {
-// The next pinned staging slot (tables_mu held): waits only if the copy that last read this slot — eight updates ago — has not finished.
-int take_update_slot(crn_handle *h, int *slot) {
-  const int i = (int)(h->upd_next++ % crn_handle::kUpdateSlots);
-  if (h->upd_used[i]) HIP_TRY(hipEventSynchronize(h->upd_done[i]));
-  h->upd_used[i] = true;
-  *slot = i;
+// Updates copy from pinned staging with hipMemcpyAsync and mark their slot with an event; a stream that is being captured into a
+// hipGraph would record both into the graph, where the event never completes for the host and every replay would upload whatever the
+// slot holds by then.  Refused: make the update outside the capture (launches capture fine: tests/test_graph.py).
+int refuse_capture(hipStream_t st, const char *what) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return crn::fail(CRN_ERR_STATE, std::string(what) + ": the stream is being captured into a hipGraph; updates cannot be captured (their pinned "
+                                                       "staging slot is reused) — make them outside the capture");
   return CRN_OK;
 }
 
-int noise_floor_locked(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, hipStream_t st) {
+// A pinned staging slot whose last copy has completed (`lk` = tables_mu, held).  Normally the first one tried; when all eight are still in
+// flight the lock is RELEASED while this thread waits for the oldest — a launch on another thread never waits for an update's copy.
+int take_update_slot(crn_handle *h, std::unique_lock<std::mutex> &lk, int *slot) {
+  for (;;) {
+    for (int k = 0; k < crn_handle::kUpdateSlots; k++) {
+      const int i = (int)((h->upd_next + k) % crn_handle::kUpdateSlots);
+      if (h->upd_used[i]) {
+        const hipError_t q = hipEventQuery(h->upd_done[i]);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("hipEventQuery(update slot): ") + hipGetErrorString(q));
+      }
+      h->upd_used[i] = true;
+      h->upd_next = i + 1;
+      *slot = i;
+      return CRN_OK;
+    }
+    const hipEvent_t oldest = h->upd_done[h->upd_next % crn_handle::kUpdateSlots];
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(oldest);
+    lk.lock();
+    if (e != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("hipEventSynchronize(update slot): ") + hipGetErrorString(e));
+  }
+}
+
+// The reduction + its read-back (nf_mu held, tables_mu NOT held: the wait stalls nobody's launch).
+int noise_floor_run(crn_handle *h, const float *d_features, int64_t n_epochs, int n_bands, float *nf_out, hipStream_t st) {
   if (!h->d_nf_scratch) HIP_TRY(hipMalloc(&h->d_nf_scratch, (crn::kNoiseFloorMaxEpochs + 1) * sizeof(float)));
   const int n = (int)std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
-  HIP_TRY(crn::launch_noise_floor(d_features, n, h->cfg.n_bands, h->d_nf_scratch, st));
+  HIP_TRY(crn::launch_noise_floor(d_features, n, n_bands, h->d_nf_scratch, st));
   HIP_TRY(hipMemcpyAsync(nf_out, h->d_nf_scratch + crn::kNoiseFloorMaxEpochs, sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CRN_OK;
 }
 
-int set_thresholds_locked(crn_handle *h, const float *thresh, int32_t n_bands, hipStream_t st) {
+int bands_of(crn_handle *h) {
+  std::lock_guard<std::mutex> lk(h->tables_mu);
+  return h->cfg.n_bands;
+}
+
+int set_thresholds_locked(crn_handle *h, std::unique_lock<std::mutex> &lk, const float *thresh, int32_t n_bands, hipStream_t st) {
   int slot = 0;
-  if (int rc = take_update_slot(h, &slot)) return rc;
+  if (int rc = take_update_slot(h, lk, &slot)) return rc;
   std::memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
   float *src = h->upd[slot].thresh;
   std::memcpy(src, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS);
@@ -828,15 +880,15 @@ int set_thresholds_locked(crn_handle *h, const float *thresh, int32_t n_bands, h
 int crn_noise_floor_device(crn_handle *h, const float *d_features, int64_t n_epochs, float *nf_out, void *stream) {
   if (!h || !d_features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
   if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
-  std::lock_guard<std::mutex> lk(h->tables_mu);
-  HIP_TRY(hipSetDevice(h->cfg.device));
-  return noise_floor_locked(h, d_features, n_epochs, nf_out, static_cast<hipStream_t>(stream));
+  std::lock_guard<std::mutex> nf(h->nf_mu);
+  HIP_TRY(hipSetDevice(h->device));
+  return noise_floor_run(h, d_features, n_epochs, bands_of(h), nf_out, static_cast<hipStream_t>(stream));
 }
 
 int crn_sense_reserve_noise_floor(crn_handle *h) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
-  std::lock_guard<std::mutex> lk(h->tables_mu);
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::lock_guard<std::mutex> nf(h->nf_mu);
+  HIP_TRY(hipSetDevice(h->device));
   const size_t bytes = (size_t)crn::kNoiseFloorMaxEpochs * CRN_MAX_BANDS * sizeof(float);   // any band plan the handle may get later
   if (!h->d_nf_scratch) HIP_TRY(hipMalloc(&h->d_nf_scratch, (crn::kNoiseFloorMaxEpochs + 1) * sizeof(float)));
   if (!h->h_nf_features) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_nf_features), bytes, hipHostMallocDefault));
@@ -846,33 +898,44 @@ int crn_sense_reserve_noise_floor(crn_handle *h) {
 
 int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream) {
   if (!h || !thresh) return crn::fail(CRN_ERR_ARG, "null handle / thresholds");
-  std::lock_guard<std::mutex> lk(h->tables_mu);
+  if (int rc = refuse_capture(static_cast<hipStream_t>(stream), "crn_sense_set_thresholds")) return rc;
+  std::unique_lock<std::mutex> lk(h->tables_mu);
   if (n_bands != h->cfg.n_bands) return crn::fail(CRN_ERR_ARG, "n_bands differs from the handle's");
-  HIP_TRY(hipSetDevice(h->cfg.device));
-  return set_thresholds_locked(h, thresh, n_bands, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipSetDevice(h->device));
+  return set_thresholds_locked(h, lk, thresh, n_bands, static_cast<hipStream_t>(stream));
 }
 
 int crn_sense_calibrate_thresholds(crn_handle *h, const float *features, int64_t n_epochs, float lambda, float *nf_out, void *stream) {
   if (!h || !features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
   if (n_epochs < 1 || n_epochs > crn::kNoiseFloorMaxEpochs) return crn::fail(CRN_ERR_ARG, "n_epochs must be in 1..4096");
   if (!(lambda > 0.f)) return crn::fail(CRN_ERR_ARG, "lambda must be positive");
-  std::lock_guard<std::mutex> lk(h->tables_mu);
-  if (!h->h_nf_features || !h->d_nf_features || !h->d_nf_scratch)
-    return crn::fail(CRN_ERR_STATE, "crn_sense_calibrate_thresholds: call crn_sense_reserve_noise_floor first (this call allocates nothing)");
-  HIP_TRY(hipSetDevice(h->cfg.device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t bytes = (size_t)n_epochs * h->cfg.n_bands * sizeof(float);
-  std::memcpy(h->h_nf_features, features, bytes);
-  HIP_TRY(hipMemcpyAsync(h->d_nf_features, h->h_nf_features, bytes, hipMemcpyHostToDevice, st));
-  if (int rc = noise_floor_locked(h, h->d_nf_features, n_epochs, nf_out, st)) return rc;
+  if (int rc = refuse_capture(st, "crn_sense_calibrate_thresholds")) return rc;
+  int n_bands = 0;
+  {
+    // upload + reduction + the wait for its result under the noise-floor buffers' own lock: launches on other threads (an ingest ring's
+    // launcher calls this between batches; the owner of the handle may be launching) are not held up by a stream drain
+    std::lock_guard<std::mutex> nf(h->nf_mu);
+    if (!h->h_nf_features || !h->d_nf_features || !h->d_nf_scratch)
+      return crn::fail(CRN_ERR_STATE, "crn_sense_calibrate_thresholds: call crn_sense_reserve_noise_floor first (this call allocates nothing)");
+    HIP_TRY(hipSetDevice(h->device));
+    n_bands = bands_of(h);
+    const size_t bytes = (size_t)n_epochs * n_bands * sizeof(float);
+    std::memcpy(h->h_nf_features, features, bytes);
+    HIP_TRY(hipMemcpyAsync(h->d_nf_features, h->h_nf_features, bytes, hipMemcpyHostToDevice, st));
+    if (int rc = noise_floor_run(h, h->d_nf_features, n_epochs, n_bands, nf_out, st)) return rc;
+  }
   float thr[CRN_MAX_BANDS];
-  for (int b = 0; b < h->cfg.n_bands; b++) thr[b] = lambda * *nf_out;
-  return set_thresholds_locked(h, thr, h->cfg.n_bands, st);
+  for (int b = 0; b < n_bands; b++) thr[b] = lambda * *nf_out;
+  std::unique_lock<std::mutex> lk(h->tables_mu);
+  if (n_bands != h->cfg.n_bands) return crn::fail(CRN_ERR_STATE, "crn_sense_calibrate_thresholds: the band plan changed while the noise floor was being estimated");
+  return set_thresholds_locked(h, lk, thr, n_bands, st);
 }
 
 int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[6][4], double threshold, void *stream) {
   if (!h || !w_ih || !w_ho) return crn::fail(CRN_ERR_ARG, "null handle / weights");
-  std::lock_guard<std::mutex> lk(h->tables_mu);
+  if (int rc = refuse_capture(static_cast<hipStream_t>(stream), "crn_sense_set_ann")) return rc;
+  std::unique_lock<std::mutex> lk(h->tables_mu);
   if (h->cfg.decide != CRN_DECIDE_ANN) return crn::fail(CRN_ERR_STATE, "crn_sense_set_ann: the handle does not decide with the network");
   if (!(threshold > 0.0 && threshold < 1.0)) return crn::fail(CRN_ERR_ARG, "threshold must be in (0, 1)");
   for (int i = 0; i < 5; i++)
@@ -881,9 +944,9 @@ int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[
   for (int j = 0; j < 6; j++)
     for (int k = 0; k < 4; k++)
       if (!std::isfinite(w_ho[j][k])) return crn::fail(CRN_ERR_ARG, "non-finite weight");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   int slot = 0;
-  if (int rc = take_update_slot(h, &slot)) return rc;
+  if (int rc = take_update_slot(h, lk, &slot)) return rc;
   std::memcpy(h->cfg.ann_w_ih, w_ih, sizeof(h->cfg.ann_w_ih));
   std::memcpy(h->cfg.ann_w_ho, w_ho, sizeof(h->cfg.ann_w_ho));
   h->cfg.ann_threshold = threshold;   // rides in the launch parameters
@@ -919,7 +982,7 @@ int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs,
   if (n_bands != h->cfg.n_bands && h->n_rings.load(std::memory_order_acquire) > 0)
     return crn::fail(CRN_ERR_STATE, "crn_sense_set_bands: an ingest ring on this handle was sized for the current number of bands "
                                     "(destroy it, change the plan, create it again)");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   const crn_cfg prev = h->cfg;
   h->cfg = next;
   if (int rc = build_tables(h)) {            // a fresh slab; the old one is freed once the device is idle
@@ -931,7 +994,7 @@ int crn_sense_set_bands(crn_handle *h, const crn_band_seg *segs, int32_t n_segs,
 
 int crn_sense_synchronize(crn_handle *h, void *stream) {
   if (!h) return crn::fail(CRN_ERR_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return CRN_OK;
 }
@@ -940,13 +1003,14 @@ int crn_noise_floor_host(crn_handle *h, const float *features, int64_t n_epochs,
   if (!h || !features || !nf_out) return crn::fail(CRN_ERR_ARG, "null handle / features / result");
   if (n_epochs < 1) return crn::fail(CRN_ERR_ARG, "n_epochs < 1");
   if (int rc = crn_sense_reserve_noise_floor(h)) return rc;   // allocates on the first call only
-  std::lock_guard<std::mutex> lk(h->tables_mu);
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::lock_guard<std::mutex> nf(h->nf_mu);
+  HIP_TRY(hipSetDevice(h->device));
+  const int n_bands = bands_of(h);
   const int64_t n = std::min<int64_t>(n_epochs, crn::kNoiseFloorMaxEpochs);
-  const size_t bytes = (size_t)n * h->cfg.n_bands * sizeof(float);
+  const size_t bytes = (size_t)n * n_bands * sizeof(float);
   std::memcpy(h->h_nf_features, features, bytes);
   HIP_TRY(hipMemcpyAsync(h->d_nf_features, h->h_nf_features, bytes, hipMemcpyHostToDevice, nullptr));
-  return noise_floor_locked(h, h->d_nf_features, n, nf_out, nullptr);
+  return noise_floor_run(h, h->d_nf_features, n, n_bands, nf_out, nullptr);
 }
 
 int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_rows, int32_t kind, float alpha,
@@ -956,7 +1020,7 @@ int crn_monitor_rows_device(crn_handle *h, const float *d_spectrum, int64_t n_ro
   if (kind != CRN_MONITOR_GNURADIO && kind != CRN_MONITOR_PSD) return crn::fail(CRN_ERR_ARG, "unknown monitor kind");
   if (!(alpha > 0.f && alpha <= 1.f)) return crn::fail(CRN_ERR_ARG, "alpha must be in (0, 1]");
   std::lock_guard<std::mutex> lk(h->tables_mu);
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   const double N = (double)h->cfg.fft_len;
   crn::MonitorParams p{};
   p.spectrum = d_spectrum;
@@ -981,7 +1045,7 @@ int crn_fft_forward_device(crn_handle *h, const float *d_in, int64_t n_frames, i
   if (samples_per_frame < 1 || samples_per_frame > h->cfg.fft_len)
     return crn::fail(CRN_ERR_ARG, "samples_per_frame must be in 1..fft_len");
   if (frame_stride <= 0) frame_stride = samples_per_frame;
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipSetDevice(h->device));
   crn::FftParams p{};
   p.in = reinterpret_cast<const float2 *>(d_in);
   p.out = reinterpret_cast<float2 *>(d_out);
@@ -1027,7 +1091,7 @@ int crn_synth_fill_device_ex(crn_handle *h, const crn_synth_cfg *sc, float *d_iq
   }
   std::lock_guard<std::mutex> lk(h->tables_mu);
   const crn_cfg &c = h->cfg;
-  HIP_TRY(hipSetDevice(c.device));
+  HIP_TRY(hipSetDevice(h->device));
   crn::SynthParams p{};
   p.iq = reinterpret_cast<float2 *>(d_iq);
   p.n_epochs = n_epochs;

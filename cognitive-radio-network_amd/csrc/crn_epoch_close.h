@@ -4,6 +4,24 @@
 #define CRN_EPOCH_CLOSE_H
 #include "crn_frame.h"
 
+// In-kernel time stamps exist only in the measurement build (libcrnsense_ab.so, variant 17: crn_frame_ab.h).  The shipped library's
+// hooks are empty: no stamp, no instruction.
+#ifdef CRN_AB_VARIANTS
+#include "crn_frame_ab.h"
+#else
+namespace crn {
+template <class C>
+struct CloseTrace {
+  CRN_DEV void workgroup_start(const SenseParams &, int) {}
+  CRN_DEV void enter(const SenseParams &, long long, bool, int, int) {}
+  CRN_DEV void stamp1() {}
+  CRN_DEV void stamp2() {}
+  CRN_DEV void stamp3() {}
+  CRN_DEV void leave(const SenseParams &, long long, bool, int) {}
+};
+}  // namespace crn
+#endif
+
 namespace crn {
 // ---------------------------------------------------------------------------------------------
 // Epoch close (reference .cpp:157-261 + the reset at :287-288): K-frame averages -> LDS in natural
@@ -118,47 +136,6 @@ CRN_DEV void ann_decide_team(const SenseParams &p, const lds_f64 *w_ih, const ld
   }
 }
 
-// Measurement aid of the A/B build (variant 17, tools/gpu_close_trace.py): s_memrealtime / s_memtime stamps of the block's phases,
-// written over the ann_out buffer.  In the shipped library the hooks are empty and no stamp exists.
-template <class C>
-struct CloseTrace {
-#ifdef CRN_AB_VARIANTS
-  static constexpr bool ON = (C::OPT & kTrace) != 0;
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-  __device__ __forceinline__ unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
-  // [epoch][3] uint64: entry of the group's first wave (s_memrealtime: 100 MHz, the same clock on every XCD); its later stamps as
-  // four 16-bit deltas in shader clocks (band sums done, barrier passed, features ready, exit); entry of the group's last wave
-  __device__ __forceinline__ void enter(const SenseParams &p, long long epoch, bool active, int t, int T) {
-    if constexpr (ON) {
-      unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
-      const unsigned long long wall = __builtin_amdgcn_s_memrealtime();
-      t0 = now();
-      if (active && tr != nullptr) {
-        if (t == 0) tr[epoch * 3 + 0] = wall;
-        if (t == T - 1) tr[epoch * 3 + 2] = wall;
-      }
-    }
-  }
-  __device__ __forceinline__ void stamp1() { if constexpr (ON) t1 = now(); }
-  __device__ __forceinline__ void stamp2() { if constexpr (ON) t2 = now(); }
-  __device__ __forceinline__ void stamp3() { if constexpr (ON) t3 = now(); }
-  __device__ __forceinline__ void leave(const SenseParams &p, long long epoch, bool active, int t) {
-    if constexpr (ON) {
-      unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
-      const unsigned long long t4 = now();
-      auto d16 = [&](unsigned long long x) { return (x - t0) > 0xFFFFull ? 0xFFFFull : (x - t0); };
-      if (active && tr != nullptr && t == 0) tr[epoch * 3 + 1] = d16(t1) | (d16(t2) << 16) | (d16(t3) << 32) | (d16(t4) << 48);
-    }
-  }
-#else
-  CRN_DEV void enter(const SenseParams &, long long, bool, int, int) {}
-  CRN_DEV void stamp1() {}
-  CRN_DEV void stamp2() {}
-  CRN_DEV void stamp3() {}
-  CRN_DEV void leave(const SenseParams &, long long, bool, int) {}
-#endif
-};
-
 template <class C>
 CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_base) {
   constexpr int R3 = C::R3;
@@ -171,19 +148,6 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   // lane id, so that nothing but the accumulators stays live in VGPRs across the frame loop for a
   // block that runs once per K frames: what the allocator kept for it, it spilled, and a scratch
   // reload waits on vmcnt behind the next frame's prefetch.
-#ifdef CRN_AB_VARIANTS
-  if constexpr ((C::OPT & kNoClose) != 0) {   // measurement ablation (variants 16, 18): not a sensing result
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      s += acc[i];
-      acc[i] = 0.f;
-    }
-    if (s == 123.456f && p.features != nullptr) p.features[0] = s;  // keeps the accumulation live
-    if constexpr ((C::OPT & kTrace) != 0 && G::XWAVE) __syncthreads();  // variant 18: what one barrier per epoch costs
-    return;
-  }
-#endif
   // latency-bound stretch with nothing of this wave's in flight behind it, and the workgroup's other
   // waves waiting at its barriers: outrank the butterflies (+0.6 % at N = 4096, +1.3 % at 2048; the
   // barrier-free sizes lose 0.5 % with it)
@@ -202,8 +166,8 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
   // The opaque values are 32-bit LDS offsets, not generic pointers: through a generic pointer every
   // access below became a FLAT instruction followed by s_waitcnt vmcnt(0), which also drained the
   // next frame's prefetch at every epoch close.
-  const unsigned tab_off = c.lds_base + (unsigned)((G::GROUPS * C::NBUF * Lay<C>::GROUP_CPLX + 16 * R3) * sizeof(cx));
-  const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * Lay<C>::GROUP_CPLX * sizeof(cx));
+  const unsigned tab_off = c.lds_base + (unsigned)((G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * R3) * sizeof(cx));
+  const unsigned gb_off = c.lds_base + (unsigned)grp * (unsigned)(C::NBUF * G::GROUP_CPLX * sizeof(cx));
   const lds_i32 *tab = reinterpret_cast<const lds_i32 *>(tab_off);
   const lds_f32 *thr = reinterpret_cast<const lds_f32 *>(tab_off + 416 * 4);
   const lds_f64 *w_ih = reinterpret_cast<const lds_f64 *>(tab_off + 544 * 4);  // [5][6]
@@ -228,7 +192,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
     const int sh = p.aligned_shift;   // uniform
     const int G = 1 << (sh - 4), nb = p.n_bands, al = (tid >> 4) & 3, r = m_lo & (G - 1), grp_b = m_lo >> (sh - 4);
     constexpr int kStride = 72;       // floats per a-row of partials: 72 mod 32 = 8 keeps a wave's rows on distinct banks
-    lds_f32 *mine = reinterpret_cast<lds_f32 *>(c.lds_base + (unsigned)(4 * c.wave * Lay<C>::ROW * sizeof(cx))) + al * kStride;
+    lds_f32 *mine = reinterpret_cast<lds_f32 *>(c.lds_base + (unsigned)(4 * c.wave * Geo<R3>::ROW * sizeof(cx))) + al * kStride;
     const float thr_lane = thr[tid & 63];
 #pragma unroll
     for (int d = 0; d < 16; d++) {
@@ -249,7 +213,7 @@ CRN_DEV void epoch_close(FrameCtx<C> &c, const SenseParams &p, long long epoch_b
       if (b < nb) {
 #pragma unroll
         for (int w4 = 0; w4 < 4; w4++) {
-          const lds_f32 *src = reinterpret_cast<const lds_f32 *>(c.lds_base + (unsigned)(4 * w4 * Lay<C>::ROW * sizeof(cx)));
+          const lds_f32 *src = reinterpret_cast<const lds_f32 *>(c.lds_base + (unsigned)(4 * w4 * Geo<R3>::ROW * sizeof(cx)));
           const float a0 = src[b], a1 = src[kStride + b], a2 = src[2 * kStride + b], a3 = src[3 * kStride + b];
           sum += a0;
           sum += a1;

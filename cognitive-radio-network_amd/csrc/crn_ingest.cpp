@@ -136,6 +136,8 @@ constexpr int kCalibMaxEpochs = 4096;      // crn_noise_floor_device uses at mos
 extern "C" int crn_sense_cfg_of(crn_handle *h, crn_cfg *out);
 extern "C" int crn_sense_ring_count(crn_handle *h, int delta);
 extern "C" int crn_sense_warm_stream(crn_handle *h, void *stream);
+extern "C" int crn_sense_run_device_any(crn_handle *h, const void *d_iq, int32_t bytes_per_sample, int64_t n_epochs, int32_t samples_per_frame,
+                                        int64_t epoch_stride, const crn_out *d_out, void *stream);
 
 namespace {
 
@@ -188,9 +190,7 @@ std::string enqueue(crn_ingest *g, Batch &b) {
   // disjoint frames: K packets zero-padded to N each, dense epochs; overlapped: whole frames cut from the epoch's run of P L samples
   const int32_t spf = g->overlapped ? g->cfg.fft_len : b.L;
   const int64_t stride = g->overlapped ? (int64_t)b.P * b.L : 0;
-  const int rc = g->sample_bytes == 4
-                     ? crn_sense_run_device_sc16(g->h, static_cast<const int16_t *>(src), b.launched, spf, stride, &out, g->stream)
-                     : crn_sense_run_device(g->h, static_cast<const float *>(src), b.launched, spf, stride, &out, g->stream);
+  const int rc = crn_sense_run_device_any(g->h, src, (int32_t)g->sample_bytes, b.launched, spf, stride, &out, g->stream);
   if (rc != CRN_OK) return crn_last_error();
   if (!zero_copy) e = hipMemcpyAsync(b.h_res, b.d_res, g->res_bytes, hipMemcpyDeviceToHost, g->stream);
   if (e == hipSuccess) e = hipEventRecord(b.done, g->stream);
@@ -552,10 +552,10 @@ static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, siz
     g->packets++;
     // a small batch is prewake_packets away from its hand-off: have the launcher awake by then (see prewake)
     if (++b.staged == g->prewake_at && g->prewake_at > 0) {
-      {
-        std::lock_guard<std::mutex> lk(g->mu);   // (under the lock: the launcher is either waiting or will see the flag before it waits)
-        g->prewake.store(true, std::memory_order_release);
-      }
+      // No lock: execute() holds CE_mutex here and must not queue behind the launcher for a hint.  The flag is atomic; if the launcher
+      // sits between its own test of the flag and its wait when this lands, the notification finds nobody and this batch's hand-off
+      // wakes it the ordinary way — a missed pre-wake costs that one decision ~50 us, never a result.
+      g->prewake.store(true, std::memory_order_release);
       g->cv_work.notify_one();
     }
     if (++s.npk < g->P) return CRN_OK;
@@ -572,11 +572,13 @@ static int ingest_push(crn_ingest *g, int32_t stream, const void *iq_packet, siz
 int crn_ingest_create(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch, crn_ingest **out) {
   return ingest_create(h, n_streams, samples_per_packet, epochs_per_batch, out, 8);
 }
+int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) { return ingest_push(g, stream, iq_packet, 8); }
+#ifdef CRN_WITH_SC16   // optional: rings of wire-format packets (make SC16=1 -> libcrnsense_sc16.so)
 int crn_ingest_create_sc16(crn_handle *h, int32_t n_streams, int32_t samples_per_packet, int32_t epochs_per_batch, crn_ingest **out) {
   return ingest_create(h, n_streams, samples_per_packet, epochs_per_batch, out, 4);
 }
-int crn_ingest_push(crn_ingest *g, int32_t stream, const float *iq_packet) { return ingest_push(g, stream, iq_packet, 8); }
 int crn_ingest_push_sc16(crn_ingest *g, int32_t stream, const int16_t *iq_packet) { return ingest_push(g, stream, iq_packet, 4); }
+#endif
 
 int crn_ingest_flush(crn_ingest *g) {
   if (!g) return crn::fail(CRN_ERR_ARG, "null ingest ring");

@@ -85,11 +85,13 @@ struct SynthParams {
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream, bool sc16 = false);
 int sense_num_variants();
-// Rounds of dealt frames (ceil(K / lane groups)) when sense_kernel_dealt can take this size / mode / K — N <= 1024 and the frame
-// slots fit in LDS — else 0.
-int sense_deal_rounds(int fft_len, bool mag, int frames_per_epoch);
+// Rounds of dealt frames (ceil(K / lane groups)) when sense_kernel_dealt can take this size / mode / window / K — N <= 1024, no window or
+// the periodic Hann on whole frames in energy mode, and the frame slots fit in the device's LDS per workgroup (lds_budget_bytes:
+// hipDeviceAttributeMaxSharedMemoryPerBlock, 160 KiB on gfx950) — else 0: the streaming kernel takes the launch.
+int sense_deal_rounds(int fft_len, bool mag, bool win, bool hann_whole_frames, int frames_per_epoch, size_t lds_budget_bytes);
 unsigned sense_ref_acc_mask(int fft_len);    // accumulator registers (bit j R3 + d) the reference channel plan reaches at this size
-bool sense_variant_available(int variant);   // the shipped library carries 0 (= 13), 2 and 23; libcrnsense_ab.so all of them
+bool sense_variant_available(int variant);   // the shipped library carries 0 (= 13) and 2; libcrnsense_ab.so the measurement forms too
+bool sense_variant_traces(int variant);      // a measurement form that writes time stamps over the ann_out buffer (never in the shipped library)
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk);
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block);
 struct FftParams {
@@ -119,7 +121,7 @@ hipError_t launch_monitor(const MonitorParams &p, hipStream_t stream);
 constexpr int kNoiseFloorMaxEpochs = 4096;
 hipError_t launch_noise_floor(const float *feat, int n_epochs, int nb, float *scratch, hipStream_t stream);
 hipError_t launch_synth(const SynthParams &p, hipStream_t stream);
-hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream);
+hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream);   // crn_kernels_sc16.hip (make SC16=1)
 hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream);
 hipError_t launch_nop(hipStream_t stream);   // one empty workgroup (crn_sense_warm_stream)
 

@@ -22,159 +22,133 @@
 
 namespace crn {
 
-hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream);
-
-// Kernel variants selectable through crn_sense_set_variant (0 = default).  The shipped library (libcrnsense.so) compiles the three
-// that are forms of the product — 13 (= 0, the default), 2 (no pass-3 row pruning: what any band table outside the reference plan's
-// rows runs anyway) and 23 (every twiddle in registers) — and refuses the others; libcrnsense_ab.so (-DCRN_AB_VARIANTS, used by
-// tools/ and the A/B test) compiles the whole measurement set: other schedules of the same arithmetic, the ablations that compute
-// nothing useful (11, 12, 14, 15, 16, 18) and the trace build (17).
-struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, abl, pk; };
+// Kernel forms selectable through crn_sense_set_variant (0 = default).  The shipped library (libcrnsense.so) compiles the two that are
+// forms of the product — 13 (= 0, the default) and 2 (no pass-3 row pruning: what any band table outside the reference plan's rows runs
+// anyway) — and refuses the others.  libcrnsense_ab.so (-DCRN_AB_VARIANTS; tools/ and the A/B
+// test) adds the measurement forms that are combinations of the shipped flags (7, 19-22, 26, 27) and the trace build (17:
+// crn_frame_ab.h).  The numbers are the ones profiles/ and docs/history/ quote; the schedules, ablations and layouts of rounds 1-4
+// that were measured and not kept (1, 3-6, 8-12, 14-16, 18, 23-25) are gone from the tree: docs/history/removed_variants.md.
+struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, pk; };   // nbuf == 0: no such form
 static constexpr VariantDesc kVariants[] = {
-    /* 0 (unused) */ {0, 0, 0, 0, 0, 0, 0},
-    /* 1 */ {1, 0, 1, 1, 4, 0, 1},   // 4 workgroups/CU, no explicit prefetch
-    /* 2 */ {1, 1, 1, 1, 4, 0, 1},   // the default without the pass-3 row pruning
-    /* 3 */ {1, 1, 1, 1, 3, 0, 1},   // 3 workgroups/CU, tw2 from LDS, compiler-placed loads and LDS reads
-    /* 4 */ {2, 1, 1, 0, 2, 0, 1},   // 2 workgroups/CU, two LDS buffers (one barrier per frame)
-    /* 5 */ {1, 0, 1, 1, 4, 0, 0},   // as 1 with scalar (unpacked) butterflies
-    /* 6 */ {2, 1, 1, 1, 2, 0, 1},   // frame pairs (two frames per wave in flight), tw2 from LDS
-    /* 7 */ {1, 1, 1, 1, 4, 0, 1},   // the default without the wave-priority raise in passes 1 and 2
-    /* 8 */ {1, 1, 1, 0, 3, 0, 1},   // 3 workgroups/CU, all twiddles in registers, compiler-placed loads
-    /* 9 */ {2, 1, 1, 0, 2, 0, 1},   // frame pairs, tw2 in registers
-    /* 10 */ {1, 1, 1, 0, 3, 0, 1},  // 8 + spread prefetch + ds_read_b64 blocks (what the other sizes run)
-    /* 11 */ {2, 1, 1, 0, 2, 1, 1},  // ablation: stream only
-    /* 12 */ {2, 1, 1, 0, 2, 2, 1},  // ablation: compute only, 2 workgroups/CU
-    /* 13 */ {1, 1, 1, 1, 4, 0, 1},  // default: 4 workgroups/CU, compressed tw1, tw2 from LDS, row pruning when it applies
-    /* 14 */ {1, 1, 1, 0, 3, 3, 1},  // ablation: butterflies only (no reload, no LDS exchange)
-    /* 15 */ {1, 1, 1, 0, 3, 2, 1},  // ablation: compute only, 3 workgroups/CU
-    /* 16 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: the default with the epoch close reduced to an accumulator reset
-    /* 17 */ {1, 1, 1, 1, 4, 0, 1},  // measurement aid: the default + s_memtime stamps of the epoch close in ann_out
-    /* 18 */ {1, 1, 1, 1, 4, 0, 1},  // ablation: 16 plus one workgroup barrier per epoch
-    /* 19 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: Hann folded into pass 1's first butterflies
-    /* 20 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: 19 + pass-2 twiddles read from LDS ahead of their use
-    /* 21 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: early pass-2 twiddle reads alone
-    /* 22 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the plain form (16 window registers, twiddles read where used)
-    /* 23 */ {1, 1, 1, 0, 3, 0, 1},  // the default's work at 3 workgroups/CU with all twiddles in registers (fewer instructions, less LDS)
-    /* 24 */ {1, 1, 1, 1, 4, 0, 1},  // the default with its pass-3 rows chosen at run time from the handle's band table (kRowsRT)
-    /* 25 */ {1, 1, 1, 1, 3, 0, 1},  // windowed kernels: the default + exchange 2 read back as 8 ds_read_b128 (rows of 288, slots padded to 18)
-    /* 26 */ {1, 1, 1, 0, 2, 0, 1},  // windowed kernels: pass-2 twiddles in registers (no LDS twiddle reads) at 2 workgroups per CU
-    /* 27 */ {2, 1, 1, 0, 2, 0, 1},  // windowed kernels: 26 + two exchange buffers (one barrier per frame)
+    /* 0 (unused) */ {0, 0, 0, 0, 0, 0},
+    /* 1 */ {0, 0, 0, 0, 0, 0},
+    /* 2 */ {1, 1, 1, 1, 4, 1},   // the default without the pass-3 row pruning
+    /* 3 .. 6 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
+    /* 7 */ {1, 1, 1, 1, 4, 1},   // A/B: the default without the wave-priority raise in passes 1 and 2
+    /* 8 .. 12 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
+    /* 13 */ {1, 1, 1, 1, 4, 1},  // default: 4 workgroups/CU, compressed tw1, tw2 from LDS, row pruning when it applies
+    /* 14 .. 16 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
+    /* 17 */ {1, 1, 1, 1, 4, 1},  // A/B, measurement aid: the default + s_memtime stamps of the epoch close in ann_out
+    /* 18 */ {0, 0, 0, 0, 0, 0},
+    /* 19 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: Hann folded into pass 1's first butterflies
+    /* 20 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: 19 + pass-2 twiddles read from LDS ahead of their use (what ships)
+    /* 21 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: early pass-2 twiddle reads alone
+    /* 22 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: the plain form (16 window registers, twiddles read where used)
+    /* 23 .. 25 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
+    /* 26 */ {1, 1, 1, 0, 2, 1},  // A/B, windowed kernels: pass-2 twiddles in registers (no LDS twiddle reads) at 2 workgroups per CU
+    /* 27 */ {2, 1, 1, 0, 2, 1},  // A/B, windowed kernels: 26 + two exchange buffers (one barrier per frame)
 };
 static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
+static_assert(kNumVariants == 27, "variant numbers are the ones profiles/ and docs/ quote");
 static constexpr int kDefaultVariant = 13;
 
-// The A/B set is compiled for N = 4096 only; other sizes always run the default variant.
+// Does this build of the library carry variant v?  (0 = default.)
+bool sense_variant_available(int v) {
+  if (v == 0 || v == kDefaultVariant || v == 2) return true;
+#ifdef CRN_AB_VARIANTS
+  return v == 7 || v == 17 || (v >= 19 && v <= 22) || v == 26 || v == 27;
+#else
+  return false;
+#endif
+}
+// ... and does it write time stamps over the ann_out buffer (so that the buffer must reach the kernel whatever the decision rule)?
+bool sense_variant_traces(int v) {
+#ifdef CRN_AB_VARIANTS
+  return v == 17;
+#else
+  (void)v;
+  return false;
+#endif
+}
+
+// Wire-format input: crn_kernels_sc16.hip, linked only into a library built with `make SC16=1` (a weak reference: null when absent).
+__attribute__((weak)) hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream);
+
+// The forms other than the default exist for N = 4096 only; other sizes always run the default.
 template <int R3>
 static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
   if constexpr (R3 <= 4) {   // a launch of a few epochs (crn_api.cpp sets deal_rounds): one epoch per workgroup, frames dealt to its lane groups
-    if (p.deal_rounds > 0) return win ? launch_dealt_win<R3, 0>(p, mag, stream) : launch_dealt<R3, 0>(p, mag, stream);
-  }
-#ifdef CRN_AB_VARIANTS
-  if constexpr (R3 == 16) {
-    if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && variant >= 25 && variant <= 27) {
-      // A/B set of the Welch kernel's LDS traffic (N = 4096): 25 wide exchange rows + ds_read_b128; 26 / 27 twiddles in registers
-      constexpr int kW = kBase | kHannSym;
-      const bool al = p.aligned_shift != 0;
-      if (variant == 25 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kW | kTw2Early | kAlignedBands | kX2Wide>>(p, stream);
-      if (variant == 25) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kW | kTw2Early | kX2Wide>>(p, stream);
-      if (variant == 26 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, 0, true, true, kW | kAlignedBands>>(p, stream);
-      if (variant == 26) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, 0, true, true, kW>>(p, stream);
-      if (al) return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, 0, true, true, kW | kAlignedBands>>(p, stream);
-      return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, 0, true, true, kW>>(p, stream);
+    if (p.deal_rounds > 0) {
+      const hipError_t e = win ? launch_dealt_win<R3, 0>(p, stream) : launch_dealt<R3, 0>(p, mag, stream);
+      if (e != hipErrorLaunchOutOfResources) return e;
+      SenseParams q = p;   // the device refused the LDS the frame slots need (crn_sense_kernel.h: launch_dealt_cfg): the streaming form takes it
+      q.deal_rounds = 0;
+      return launch_r<R3>(q, mag, win, variant, stream);
     }
   }
+#ifdef CRN_AB_VARIANTS   // measurement forms of the windowed kernels: combinations of the shipped flags
+  if constexpr (R3 == 16) {
+    if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant == 26 || variant == 27)) {
+      // the Welch kernel with its pass-2 twiddles in registers, 2 workgroups per CU: 26 one exchange buffer, 27 two
+      constexpr int kW = kBase | kHannSym;
+      const bool al = p.aligned_shift != 0;
+      if (variant == 26 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, true, true, kW | kAlignedBands>>(p, stream);
+      if (variant == 26) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, true, true, kW>>(p, stream);
+      if (al) return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, true, true, kW | kAlignedBands>>(p, stream);
+      return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, true, true, kW>>(p, stream);
+    }
+    if (variant == 17 && win && !mag && p.L == Geo<R3>::N)  // close stamps for the windowed / Welch kernel
+      return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kTrace>>(p, stream);
+  }
   if (win && !mag && p.L == Geo<R3>::N && variant >= 19 && variant <= 22) {
-    // A/B set of the windowed kernel: 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2
-    // twiddle reads, 21 early twiddle reads alone, 22 the plain windowed kernel
-    if (variant == 19 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym>>(p, stream);
-    if (variant == 20 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
-    if (variant == 21) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kTw2Early>>(p, stream);
-    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase>>(p, stream);
+    // 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2 twiddle reads, 21 early twiddle reads alone, 22 the
+    // plain windowed kernel
+    if (variant == 19 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym>>(p, stream);
+    if (variant == 20 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
+    if (variant == 21) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kTw2Early>>(p, stream);
+    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase>>(p, stream);
   }
 #endif
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
   // window registers fewer; the A/B numbers are in docs/history/DESIGN_r03.md §5)
-  // (variants 2 and 23 are forms of the plain kernel: a windowed handle that selects them runs its default, not the table-window form)
-  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N &&
-      (variant <= 0 || variant > kNumVariants || variant == kDefaultVariant || variant == 2 || variant == 23)) {
+  // (a windowed handle runs this whatever plain-kernel form it selects)
+  if (win && !mag && p.hann_sym && p.L == Geo<R3>::N) {
     if constexpr (R3 == 16) {  // the Welch scan's plan (equal contiguous bands): band sums without the spectrum image
       if (p.aligned_shift != 0)
-        return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);
+        return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym | kTw2Early | kAlignedBands>>(p, stream);
     }
-    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
+    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
   }
-  if (variant <= 0 || variant > kNumVariants || R3 != 16 || mag || (win && variant != 17) || p.L != Geo<R3>::N)
-    variant = kDefaultVariant;
   // The plain 4096-point kernel runs 4 workgroups per CU with the compressed pass-1 table and pass 2
   // from LDS; everything else 3 per CU (windowed kernels carry 16 more registers: the window).
-  if constexpr (R3 != 16) {
-    // 3 workgroups per CU, all 30 twiddles in registers (4 per CU with the compressed tables was
-    // measured at these sizes: equal at 1024, -3 % at 512, -7 % at 2048), streaming workgroups
-    // (+2.5-3 % everywhere; N = 1024 used to spill with them until the epoch close was slimmed).
-    // windowed kernels (16 window registers, and for Welch three half-frame sets) read the pass-2
-    // twiddles from LDS, like the 4096-point ones: in registers they spill inside the frame loop
-    if (win) return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
-    return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
-  } else {
-    // Windowed 4096-point kernels read the pass-2 twiddles from LDS: with them in registers the
-    // Welch stream (three half-frame sets live across the epoch close) spills inside the frame loop.
-#ifdef CRN_AB_VARIANTS
-    if (variant == 17 && win && !mag && p.L == Geo<R3>::N)  // measurement aid: close stamps for the windowed / Welch kernel
-      return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, 0, true, true, kSpread | kLdsBlk | kPrioValu | kMulti | kTrace>>(p, stream);
-#endif
-    if (win)
-      return launch_default<R3, 1, true, true, true, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 2>(p, mag, win, stream);
-    if (variant == kDefaultVariant && (mag || p.L != Geo<R3>::N))
-      return launch_default<R3, 1, true, true, false, 3, true, kSpread | kLdsBlk | kPrioValu | kMulti, 1>(p, mag, win, stream);
+  // 3 workgroups per CU, all 30 twiddles in registers at N < 4096 (4 per CU with the compressed tables was
+  // measured at these sizes: equal at 1024, -3 % at 512, -7 % at 2048), streaming workgroups
+  // (+2.5-3 % everywhere; N = 1024 used to spill with them until the epoch close was slimmed).
+  // Windowed kernels (16 window registers, and for Welch three half-frame sets) read the pass-2
+  // twiddles from LDS at every size: in registers they spill inside the frame loop.
+  if (win) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2>(p, mag, win, stream);
+  if (R3 != 16 || mag || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, false, 3, true, kBase, 1, true, R3 != 16>(p, mag, win, stream);
+  if constexpr (R3 == 16) {
+    if (!sense_variant_available(variant) || variant == 0) variant = kDefaultVariant;
+    constexpr int kPlain = kSpread | kLdsBlk | kTw1C | kMulti;
+    const bool regb = reg_bands(p), ref_rows = regb && (p.acc_mask & ~kRefPlanRows) == 0;
     switch (variant) {
+      case 2:   // no pruning
+        if (regb) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu>(p, mag, win, stream);
 #ifdef CRN_AB_VARIANTS
-      case 1: return launch_rn<R3, 1, false, true, true, 4, 0, true>(p, mag, win, stream);
+      case 7:   // the default without the wave-priority raise
+        if (ref_rows) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, true, kPlain>(p, mag, win, stream);
+      case 17:  // the default + time stamps
+        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kPrioValu | kRegBands | kTrace>(p, mag, win, stream);
 #endif
-      case 2:
-        if (reg_bands(p))
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
-#ifdef CRN_AB_VARIANTS
-      case 3: return launch_rn<R3, 1, true, true, true, 3, 0, true>(p, mag, win, stream);
-      case 4: return launch_rn<R3, 2, true, true, false, 2, 0, true>(p, mag, win, stream);
-      case 5: return launch_rn<R3, 1, false, true, true, 4, 0, false>(p, mag, win, stream);
-      case 6: return launch_rn<R3, 2, true, true, true, 2, 0, true, kPair>(p, mag, win, stream);
-      case 7:
-        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kMulti | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kMulti>(p, mag, win, stream);
-      case 8: return launch_rn<R3, 1, true, true, false, 3, 0, true>(p, mag, win, stream);
-      case 9: return launch_rn<R3, 2, true, true, false, 2, 0, true, kPair>(p, mag, win, stream);
-      case 10: return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk>(p, mag, win, stream);
-      case 11: return launch_rn<R3, 2, true, true, false, 2, 1, true>(p, mag, win, stream);
-      case 12: return launch_rn<R3, 2, true, true, false, 2, 2, true>(p, mag, win, stream);
-#endif
-      case 13:
-        // the reference channel plan's rows only, unless the caller wants the per-bin spectrum
-        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
-        if (reg_bands(p))
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
-#ifdef CRN_AB_VARIANTS
-      case 14: return launch_rn<R3, 1, true, true, false, 3, 3, true>(p, mag, win, stream);
-      case 15: return launch_rn<R3, 1, true, true, false, 3, 2, true>(p, mag, win, stream);
-      case 17: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kTrace>(p, mag, win, stream);
-      case 18: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose | kTrace>(p, mag, win, stream);
-      case 16: return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRows | kPrioValu | kMulti | kRegBands | kNoClose>(p, mag, win, stream);
-#endif
-#ifdef CRN_AB_VARIANTS
-      case 24:  // rows chosen at run time (any band table with a register close); otherwise the full kernel
-        if (reg_bands(p))
-          return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kRowsRT | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, 0, true, kSpread | kLdsBlk | kTw1C | kPrioValu | kMulti>(p, mag, win, stream);
-#endif
-      case 23:  // the default's work with every twiddle in registers: 3 workgroups per CU, 14 fewer packed instructions and no LDS twiddle reads per frame
-        if (reg_bands(p) && (p.acc_mask & ~kRefPlanRows) == 0)
-          return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kRows | kPrioValu | kMulti | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, false, 3, 0, true, kSpread | kLdsBlk | kPrioValu | kMulti>(p, mag, win, stream);
+      default:  // 13: the reference channel plan's rows only, unless the plan reaches others or the caller wants the per-bin spectrum
+        if (ref_rows) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kPrioValu | kRegBands>(p, mag, win, stream);
+        if (regb) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu | kRegBands>(p, mag, win, stream);
+        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu>(p, mag, win, stream);
     }
   }
   return hipErrorInvalidValue;
@@ -182,7 +156,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
                         hipStream_t stream, bool sc16) {
-  if (sc16) return launch_sense_sc16(p, fft_len, mag, win, variant, stream);   // crn_kernels_sc16.hip
+  if (sc16) return launch_sense_sc16 ? launch_sense_sc16(p, fft_len, mag, win, variant, stream) : hipErrorNotSupported;
   switch (fft_len) {
     case 512: return launch_r<2>(p, mag, win, variant, stream);
     case 1024: return launch_r<4>(p, mag, win, variant, stream);
@@ -194,31 +168,23 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
 
 int sense_num_variants() { return kNumVariants; }
 
-int sense_deal_rounds(int fft_len, bool mag, int K) {
+int sense_deal_rounds(int fft_len, bool mag, bool win, bool hann_whole_frames, int K, size_t lds_budget) {
   if (fft_len != 512 && fft_len != 1024) return 0;
+  if (win && (mag || !hann_whole_frames)) return 0;   // the one windowed dealt form: periodic Hann, energy mode, whole frames
   const int r3 = fft_len / 256, t = 16 * r3, groups = 256 / t;
   if (K < 2) return 0;   // one frame: nothing to deal
   const int rounds = (K + groups - 1) / groups;
   const size_t lds = ((size_t)groups * 16 * (t + r3) + 16 * r3) * sizeof(cx) + kCloseLdsBytes + (size_t)rounds * groups * fft_len * (mag ? 4 : 8);
-  return lds <= 160 * 1024 ? rounds : 0;
+  return lds <= lds_budget ? rounds : 0;
 }
 unsigned sense_ref_acc_mask(int fft_len) { return ref_acc_mask(fft_len / 256); }
-
-// Does this build of the library carry variant v?  (0 = default.)
-bool sense_variant_available(int v) {
-#ifdef CRN_AB_VARIANTS
-  return v >= 0 && v <= kNumVariants;
-#else
-  return v == 0 || v == kDefaultVariant || v == 2 || v == 23;
-#endif
-}
 
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) {
   if (variant < 0 || fft_len != 4096) {  // launch_default: every size / mode other than the 4096-pt plain path
     *nbuf = 1; *prefetch = 1; *nt = 1; *tw2lds = 0; *pk = 1;
     return;
   }
-  if (variant == 0 || variant > kNumVariants) variant = kDefaultVariant;
+  if (variant == 0 || variant > kNumVariants || kVariants[variant].nbuf == 0) variant = kDefaultVariant;
   *nbuf = kVariants[variant].nbuf;
   *prefetch = kVariants[variant].prefetch;
   *nt = kVariants[variant].nt;
@@ -247,7 +213,7 @@ void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int 
 // ---------------------------------------------------------------------------------------------
 template <int R3>
 __global__ __launch_bounds__(256, 2) void fft_kernel(const FftParams p) {
-  using C = Cfg<R3, 1, false, false, false, false, false, 2, 0, false, true, kLdsBlk>;
+  using C = Cfg<R3, 1, false, false, false, false, false, 2, false, true, kLdsBlk>;
   using G = Geo<R3>;
   constexpr int T = G::T, N = G::N, J = G::J;
   extern __shared__ __attribute__((aligned(16))) cx lds[];
@@ -514,27 +480,9 @@ hipError_t launch_pu_pattern(const SynthParams &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// complex floats -> the radio's wire format (int16 pairs, full scale 32768): crn_pack_sc16_device
-__global__ __launch_bounds__(256) void pack_sc16_kernel(const float2 *iq, long long n, short2 *out, float full_scale) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float2 v = iq[i];
-    out[i] = make_short2((short)fminf(fmaxf(rintf(v.x * full_scale), -32768.f), 32767.f), (short)fminf(fmaxf(rintf(v.y * full_scale), -32768.f), 32767.f));
-  }
-}
-
 __global__ void nop_kernel() {}
 hipError_t launch_nop(hipStream_t stream) {
   hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, stream);
-  return hipGetLastError();
-}
-
-hipError_t launch_pack_sc16(const float *iq, long long n_samples, short *out, float full_scale, hipStream_t stream) {
-  if (n_samples <= 0) return hipSuccess;
-  long long blocks = (n_samples + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(pack_sc16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float2 *>(iq), n_samples,
-                     reinterpret_cast<short2 *>(out), full_scale);
   return hipGetLastError();
 }
 

@@ -62,24 +62,12 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   c.a = a;
   c.m_lo = m_lo;
   c.L = p.L;
-  c.rt_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)p.acc_mask);
-  c.gbuf = lds + grp * (NBUF * Lay<C>::GROUP_CPLX);
+  c.gbuf = lds + grp * (NBUF * G::GROUP_CPLX);
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.grp_epoch_stride = 1;
   c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
-  c.tw2_lds = lds + G::GROUPS * NBUF * Lay<C>::GROUP_CPLX;  // [16][R3], TW2LDS only
-#ifdef CRN_AB_VARIANTS
-  if constexpr ((C::OPT & kTrace) != 0) {
-    // workgroup start on the wall clock, behind the [epoch][3] close stamps (the caller's buffer holds 4 words per epoch)
-    // ... and, half a buffer further, where it runs: HW_ID (wave / SIMD / CU / SE) in the low word, XCC_ID in the high one
-    if (tid == 0 && p.ann_out != nullptr) {
-      unsigned long long *tr = reinterpret_cast<unsigned long long *>(p.ann_out);
-      tr[p.n_epochs * 3 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-      tr[p.n_epochs * 3 + p.n_epochs / 2 + blockIdx.x] =
-          (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-    }
-  }
-#endif
+  c.tw2_lds = lds + G::GROUPS * NBUF * G::GROUP_CPLX;  // [16][R3], TW2LDS only
+  CloseTrace<C>::workgroup_start(p, tid);   // (measurement build only: crn_frame_ab.h)
   const int K = p.K;
   c.Kf = (float)K;
   c.invK = 1.0f / (float)K;
@@ -91,7 +79,8 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
   // A plain streaming workgroup asks for its first frame before anything else: twiddles and tables (L2 hits, but queued behind the
   // CU's streaming loads: ~4 us a round trip on a full machine) then arrive with it instead of ahead of it.  Measured from inside
   // the kernel (tools/gpu_wg_placement.py): a workgroup's first epoch took 26 us longer than its later ones.
-  constexpr bool kEarlyLoad = !C::WIN && (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH;
+  static_assert((C::OPT & kMulti) != 0 && C::PREFETCH, "the kernels are streaming workgroups with the prefetch spread through the butterflies");
+  constexpr bool kEarlyLoad = !C::WIN;
   if constexpr (kEarlyLoad) {
     const StreamSpan sp0 = stream_span<R3>(p);
     load_frame<R3, NT, SC>(ua, group_rsrc<R3, (int)SB>(p, sp0.g0, sp0.epw), voff, 0u, C::FULL ? G::N : c.L);
@@ -117,7 +106,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     // band table -> LDS (2 KiB behind the exchange buffers and the tw2 table): the epoch close walks
     // it, and from global memory every walk step was a dependent ~1 us vector load.  Every load of the prologue is issued before the
     // first LDS write (unconditional loads, clamped indices): one wait for all of them instead of three round trips in a row.
-    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * Lay<C>::GROUP_CPLX + 16 * R3);
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * NBUF * G::GROUP_CPLX + 16 * R3);
     const int w0 = p.band_tab[tid], w1 = p.band_tab[tid + 256];
     const int w2 = p.band_tab[tid < kBandTabWords - 512 ? tid + 512 : kBandTabWords - 1];  // row entries
     [[maybe_unused]] cx tw2v = cx{0.f, 0.f};
@@ -126,18 +115,14 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
     tab[tid + 256] = w1;
     if (tid < kBandTabWords - 512) tab[tid + 512] = w2;
     if constexpr (C::TW2LDS) {
-      if (tid < 16 * R3) lds[G::GROUPS * NBUF * Lay<C>::GROUP_CPLX + tid] = tw2v;
+      if (tid < 16 * R3) lds[G::GROUPS * NBUF * G::GROUP_CPLX + tid] = tw2v;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 16; i++) c.acc[i] = 0.f;
 
-#ifdef CRN_AB_VARIANTS
-  [[maybe_unused]] cx u0[16];   // ablations that do not re-load: the first frame, kept
-#endif
-
-  if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH && (C::OPT & kMulti) != 0) {
+  if constexpr (C::WIN) {
     if (p.frame_stride * 2 == G::N && p.epoch_stride == (long long)K * (G::N / 2)) {
       // Welch (hop = N/2) over dense epochs: a lane group's epochs are one uninterrupted stream of
       // half-frames H(g) = samples [g N/2, (g+1) N/2) — frame g = H(g) | H(g+1), and the half an epoch
@@ -170,7 +155,7 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
           ub[r] = LO[r];                                                                            \
           ub[8 + r] = HI[r];                                                                        \
         }                                                                                           \
-        frame_compute<C, true, true>(ub, c, f, &IN, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere); \
+        frame_compute<C, true>(ub, c, f, IN, rs, voff, g + 1 < F ? (unsigned)(g + 2) * hbytes : kNowhere); \
         if (++f == K) {                                                                             \
           f = 0;                                                                                    \
           epoch_close<C>(c, p, sp.g0 * G::GROUPS + j);                                              \
@@ -189,153 +174,76 @@ __global__ __launch_bounds__(256, C::OCC) void sense_kernel(const SenseParams p)
       return;
     }
   }
-  {
+  if constexpr (C::WIN) {
+    // (windowed kernels ask for their first frame after the tables; Welch over epochs with gaps between them runs one epoch group
+    // per workgroup)
     const long long epoch_base = (long long)blockIdx.x * G::GROUPS;
     const __amdgpu_buffer_rsrc_t rsrc = group_rsrc<R3, (int)SB>(p, blockIdx.x);
-    if constexpr (!kEarlyLoad) load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);   // one epoch group per workgroup
-#ifdef CRN_AB_VARIANTS
-    if constexpr (C::ABL >= 2) {
+    load_frame<R3, NT, SC>(ua, rsrc, voff, 0u, C::FULL ? G::N : c.L);
+    if (p.frame_stride * 2 == G::N) {
+      // Welch, hop = N/2: frame f = halves H(f) | H(f+1) with H(j) = samples [j N/2, (j+1) N/2).
+      // Three half-frame register sets: two hold the current frame's raw samples, the third
+      // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
+      // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
+      constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
+      cx h0[8], h1[8], hn[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) u0[r] = ua[r];
-    }
-#endif
-    if constexpr (C::WIN && C::ABL == 0 && C::PREFETCH) {
-      if (p.frame_stride * 2 == G::N) {
-        // Welch, hop = N/2: frame f = halves H(f) | H(f+1) with H(j) = samples [j N/2, (j+1) N/2).
-        // Three half-frame register sets: two hold the current frame's raw samples, the third
-        // receives H(f+2) while frame f is computed, so every sample is fetched from HBM once per
-        // epoch.  (ua was loaded as a whole frame above: its two halves are H(0) and H(1).)
-        constexpr unsigned hbytes = (unsigned)(G::N / 2) * SB;
-        cx h0[8], h1[8], hn[16];
+      for (int r = 0; r < 8; r++) {
+        h0[r] = ua[r];
+        h1[r] = ua[8 + r];
+      }
+      for (int f = 0; f < K; f++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-          h0[r] = ua[r];
-          h1[r] = ua[8 + r];
+          ub[r] = h0[r];
+          ub[8 + r] = h1[r];
         }
-        for (int f = 0; f < K; f++) {
+        // H(f+2) is fetched from inside frame f's first pass, one load per radix-4 group
+        frame_compute<C, true>(ub, c, f, hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
 #pragma unroll
-          for (int r = 0; r < 8; r++) {
-            ub[r] = h0[r];
-            ub[8 + r] = h1[r];
-          }
-          // H(f+2) is fetched from inside frame f's first pass, one load per radix-4 group
-          frame_compute<C, true, true>(ub, c, f, &hn, rsrc, voff, f + 1 < K ? (unsigned)(f + 2) * hbytes : kNowhere);
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            h0[r] = h1[r];
-            h1[r] = hn[r];
-          }
+        for (int r = 0; r < 8; r++) {
+          h0[r] = h1[r];
+          h1[r] = hn[r];
         }
-        epoch_close<C>(c, p, epoch_base);
-        return;
-      }
-    }
-#ifdef CRN_AB_VARIANTS   // frame pairs (kPair) and one epoch group per workgroup: forms the shipped dispatch never selects
-    if constexpr ((C::OPT & kPair) != 0 && C::ABL == 0 && C::NBUF == 2) {
-      // Frame pairs, two pairs per iteration in ping-pong: (ua, ub) and (uc, ud).
-      cx uc[16], ud[16];
-      load_frame<R3, NT, SC>(ub, rsrc, voff, K > 1 ? fbytes : kNowhere);
-      int f = 0;
-      for (; f + 3 < K; f += 4) {
-        load_frame<R3, NT, SC>(uc, rsrc, voff, (unsigned)(f + 2) * fbytes);
-        load_frame<R3, NT, SC>(ud, rsrc, voff, (unsigned)(f + 3) * fbytes);
-        frame_pair_compute<C>(ua, ub, c);
-        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 4 < K ? (unsigned)(f + 4) * fbytes : kNowhere);
-        load_frame<R3, NT, SC>(ub, rsrc, voff, f + 5 < K ? (unsigned)(f + 5) * fbytes : kNowhere);
-        frame_pair_compute<C>(uc, ud, c);
-      }
-      const int rem = K - f;  // 0..3 frames left, the first two of them already in (ua, ub)
-      if (rem >= 2) {
-        load_frame<R3, NT, SC>(uc, rsrc, voff, rem == 3 ? (unsigned)(f + 2) * fbytes : kNowhere);
-        frame_pair_compute<C>(ua, ub, c);
-        if (rem == 3) {
-          group_sync<C>();
-          frame_compute<C>(uc, c, 0);
-        }
-      } else if (rem == 1) {
-        group_sync<C>();
-        frame_compute<C>(ua, c, 0);
       }
       epoch_close<C>(c, p, epoch_base);
       return;
     }
-    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) == 0 && C::ABL == 0 && C::PREFETCH) {
-      // One epoch group per workgroup; frame f+1's loads are issued from inside frame f's butterflies.
-      int f = 0;
-      for (; f + 1 < K; f += 2) {
-        frame_compute<C, true>(ua, c, f, &ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
-        frame_compute<C, true>(ub, c, f + 1, &ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
-      }
-      if (f < K) frame_compute<C>(ua, c, f);
-      epoch_close<C>(c, p, epoch_base);
-      return;
-    }
-#endif
-    if constexpr ((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH) {
-      // This workgroup owns p.groups_per_wg consecutive epoch groups and treats their frames as
-      // one stream: twiddles are loaded once, and the first frame of the next epoch is already in
-      // flight while the last frame of this one is computed and closed (the per-workgroup prologue
-      // and the exposed first load cost ~6 % at one epoch per workgroup).  Two register sets in
-      // ping-pong; frame f+1's loads are issued from inside frame f's butterflies.
-      // Workgroups are dispatched in blockIdx order; the last ones take a single epoch group, so the
-      // machine drains in steps of one epoch instead of one 4-epoch workgroup (measured with
-      // s_memrealtime stamps: the last 1024 workgroups used to finish spread over 200 us of a
-      // 1.4 ms kernel).
-      const StreamSpan sp = stream_span<R3>(p);
-      const int epw = sp.epw, n_local = sp.n_local;
-      const long long g0 = sp.g0;
-      const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
-      const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
-      if constexpr (!kEarlyLoad) load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);   // windowed kernels: after the tables
-      int j = 0, f = 0;
-#define CRN_STREAM_STEP(CUR, NXT)                                                                   \
-      {                                                                                             \
-        const bool last = f + 1 == K;                                                               \
-        const int j_n = last ? j + 1 : j;                                                           \
-        const int f_n = last ? 0 : f + 1;                                                           \
-        const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
-        frame_compute<C, true>(CUR, c, f, &NXT, rs, voff, soff_n);                                   \
-        if (last) {                                                                                 \
-          epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                               \
-        }                                                                                           \
-        j = j_n;                                                                                    \
-        f = f_n;                                                                                    \
-      }
-      while (true) {
-        CRN_STREAM_STEP(ua, ub)
-        if (j >= n_local) break;
-        CRN_STREAM_STEP(ub, ua)
-        if (j >= n_local) break;
-      }
-#undef CRN_STREAM_STEP
-      return;
-    }
-#ifndef CRN_AB_VARIANTS
-    static_assert((C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH,
-                  "shipped kernels are streaming workgroups with the prefetch spread through the butterflies");
-#else
-    if constexpr (C::PREFETCH && C::ABL < 2) {
-      // Two register sets in ping-pong: while frame f is computed from one set, frame f+1 lands in
-      // the other.  Always 16 loads per step, so the compiler waits with a counted vmcnt; after the
-      // last frame they point outside the window and fetch nothing.
-      int f = 0;
-      for (; f + 1 < K; f += 2) {
-        load_frame<R3, NT, SC>(ub, rsrc, voff, (unsigned)(f + 1) * fbytes);
-        frame_step<C>(ua, c, f, u0);
-        load_frame<R3, NT, SC>(ua, rsrc, voff, f + 2 < K ? (unsigned)(f + 2) * fbytes : kNowhere);
-        frame_step<C>(ub, c, f + 1, u0);
-      }
-      if (f < K) frame_step<C>(ua, c, f, u0);
-    } else {
-      for (int f = 0; f < K; f++) {
-        frame_step<C>(ua, c, f, u0);
-        if constexpr (C::ABL < 2)
-          load_frame<R3, NT, SC>(ua, rsrc, voff, f + 1 < K ? (unsigned)(f + 1) * fbytes : kNowhere);
-      }
-    }
-    epoch_close<C>(c, p, epoch_base);
-#endif
   }
+  // This workgroup owns p.groups_per_wg consecutive epoch groups and treats their frames as
+  // one stream: twiddles are loaded once, and the first frame of the next epoch is already in
+  // flight while the last frame of this one is computed and closed (the per-workgroup prologue
+  // and the exposed first load cost ~6 % at one epoch per workgroup).  Two register sets in
+  // ping-pong; frame f+1's loads are issued from inside frame f's butterflies.
+  // Workgroups are dispatched in blockIdx order; the last ones take a single epoch group, so the
+  // machine drains in steps of one epoch instead of one 4-epoch workgroup (measured with
+  // s_memrealtime stamps: the last 1024 workgroups used to finish spread over 200 us of a
+  // 1.4 ms kernel).
+  const StreamSpan sp = stream_span<R3>(p);
+  const int epw = sp.epw, n_local = sp.n_local;
+  const long long g0 = sp.g0;
+  const __amdgpu_buffer_rsrc_t rs = group_rsrc<R3, (int)SB>(p, g0, epw);
+  const unsigned gbytes = (unsigned)(G::GROUPS * (unsigned)p.epoch_stride) * SB;
+  if constexpr (!kEarlyLoad) load_frame<R3, NT, SC>(ua, rs, voff, 0u, C::FULL ? G::N : c.L);   // windowed kernels: after the tables
+  int j = 0, f = 0;
+#define CRN_STREAM_STEP(CUR, NXT)                                                                 \
+  {                                                                                               \
+    const bool last = f + 1 == K;                                                                 \
+    const int j_n = last ? j + 1 : j;                                                             \
+    const int f_n = last ? 0 : f + 1;                                                             \
+    const unsigned soff_n = j_n < n_local ? (unsigned)j_n * gbytes + (unsigned)f_n * fbytes : kNowhere; \
+    frame_compute<C>(CUR, c, f, NXT, rs, voff, soff_n);                                           \
+    if (last) epoch_close<C>(c, p, (g0 + j) * G::GROUPS);                                         \
+    j = j_n;                                                                                      \
+    f = f_n;                                                                                      \
+  }
+  while (true) {
+    CRN_STREAM_STEP(ua, ub)
+    if (j >= n_local) break;
+    CRN_STREAM_STEP(ub, ua)
+    if (j >= n_local) break;
+  }
+#undef CRN_STREAM_STEP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -357,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
   constexpr unsigned SB = C::SB;
   using G = Geo<R3>;
   constexpr int T = G::T;
-  static_assert(!G::XWAVE && C::NBUF == 1 && !C::TW2LDS && (C::OPT & kDeal) != 0 && (C::OPT & kSpread) != 0 && C::ABL == 0,
+  static_assert(!G::XWAVE && C::NBUF == 1 && !C::TW2LDS && (C::OPT & kDeal) != 0,
                 "dealt frames: N <= 1024, twiddles in registers");
   extern __shared__ __attribute__((aligned(16))) cx lds[];
 
@@ -370,11 +278,10 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
   c.a = t / R3;
   c.m_lo = t % R3;
   c.L = p.L;
-  c.rt_mask = 0xFFFFu;
-  c.gbuf = lds + grp * Lay<C>::GROUP_CPLX;
+  c.gbuf = lds + grp * G::GROUP_CPLX;
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset(lds));
-  c.tw2_lds = lds + G::GROUPS * Lay<C>::GROUP_CPLX;
+  c.tw2_lds = lds + G::GROUPS * G::GROUP_CPLX;
   // only lane group 0 holds an epoch when the close runs: the others' epoch index lands past the batch (inactive)
   c.grp_epoch_stride = (int)p.n_epochs;
   const int K = p.K;
@@ -409,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
     for (int r = 0; r < 16; r++) c.win[r] = p.window[t + T * r];
   }
   {
-    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * Lay<C>::GROUP_CPLX + 16 * R3);
+    int *tab = reinterpret_cast<int *>(lds + G::GROUPS * G::GROUP_CPLX + 16 * R3);
     const int w0 = p.band_tab[tid], w1 = p.band_tab[tid + 256];
     const int w2 = p.band_tab[tid < kBandTabWords - 512 ? tid + 512 : kBandTabWords - 1];
     tab[tid] = w0;
@@ -422,13 +329,13 @@ __global__ __launch_bounds__(256, 1) void sense_kernel_dealt(const SenseParams p
   // frame slots behind everything the streaming kernel keeps in LDS: [rounds x GROUPS][16][T] values
   constexpr unsigned kSlotBytes = (unsigned)G::N * (C::MAG ? 4u : 8u);
   const unsigned park_base =
-      c.lds_base + (unsigned)((G::GROUPS * Lay<C>::GROUP_CPLX + 16 * R3) * sizeof(cx)) + (unsigned)kCloseLdsBytes;
+      c.lds_base + (unsigned)((G::GROUPS * G::GROUP_CPLX + 16 * R3) * sizeof(cx)) + (unsigned)kCloseLdsBytes;
   int r = 0;
 #define CRN_DEAL_STEP(CUR, NXT)                                                                       \
   {                                                                                                   \
     const int f = r * G::GROUPS + grp, fn = f + G::GROUPS;                                            \
     c.park_off = park_base + (unsigned)f * kSlotBytes;                                                \
-    frame_compute<C, true>(CUR, c, 0, &NXT, rs, voff, (r + 1 < rounds && fn < K) ? (unsigned)fn * fbytes : kNowhere); \
+    frame_compute<C>(CUR, c, 0, NXT, rs, voff, (r + 1 < rounds && fn < K) ? (unsigned)fn * fbytes : kNowhere); \
     r++;                                                                                              \
   }
   while (true) {
@@ -447,7 +354,7 @@ template <class C>
 static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
   using G = Geo<C::R3>;
   const size_t slot_bytes = (size_t)G::N * (C::MAG ? 4 : 8);
-  const size_t lds = ((size_t)G::GROUPS * Lay<C>::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes +
+  const size_t lds = ((size_t)G::GROUPS * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes +
                      (size_t)p.deal_rounds * G::GROUPS * slot_bytes;
   if (p.n_epochs <= 0) return hipSuccess;
   auto kfn = sense_kernel_dealt<C>;
@@ -459,7 +366,10 @@ static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
     std::atomic<size_t> &a = allowed[dev & 63];
     if (a.load(std::memory_order_acquire) < lds) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
+      if (e != hipSuccess) {   // a device (or partition) with less LDS than crn_sense_create was told: the caller launches the streaming form
+        (void)hipGetLastError();
+        return hipErrorLaunchOutOfResources;
+      }
       a.store(lds, std::memory_order_release);
     }
   }
@@ -467,16 +377,14 @@ static hipError_t launch_dealt_cfg(const SenseParams &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Windowed dealt-frame forms, mirroring what the streaming dispatch picks for the same launch (so that the arithmetic is the same,
-// bit for bit): periodic Hann on whole frames in energy mode rides in pass 1's first butterflies (kHannSym); every other window,
-// mode and frame length multiplies by the table.  Windowed kernels close through the LDS walk.
+// The windowed dealt-frame form: periodic Hann on whole frames in energy mode, riding in pass 1's first butterflies (kHannSym) exactly as
+// the streaming dispatch picks it for the same launch, so that the arithmetic is the same bit for bit — what the engine's `-m welch` /
+// `-m scan` launch.  (Other windows and |X| mode have no dealt form: sense_deal_rounds says 0 and the streaming kernel takes the launch.)
+// Windowed kernels close through the LDS walk.
 template <int R3, int OPT>
-static hipError_t launch_dealt_win(const SenseParams &p, bool mag, hipStream_t stream) {
+static hipError_t launch_dealt_win(const SenseParams &p, hipStream_t stream) {
   constexpr int kO = kSpread | kLdsBlk | kDeal | OPT;
-  if (!mag && p.hann_sym && p.L == Geo<R3>::N)
-    return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, 0, false, true, kO | kHannSym>>(p, stream);
-  if (mag) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, true, false, 1, 0, false, true, kO>>(p, stream);
-  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, 0, false, true, kO>>(p, stream);
+  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, false, true, kO | kHannSym>>(p, stream);
 }
 
 // Dealt-frame forms of a size: |X| or energy, band sums from registers or through the LDS walk; short frames are masked at run time.
@@ -485,11 +393,11 @@ static hipError_t launch_dealt(const SenseParams &p, bool mag, hipStream_t strea
   constexpr int kO = kSpread | kLdsBlk | kDeal | OPT;
   const bool regb = p.n_row_entries > 0 && p.spectrum == nullptr;
   if (mag) {
-    if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, 0, false, true, kO | kRegBands>>(p, stream);
-    return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, 0, false, true, kO>>(p, stream);
+    if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, false, true, kO | kRegBands>>(p, stream);
+    return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, false, true, kO>>(p, stream);
   }
-  if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, 0, false, true, kO | kRegBands>>(p, stream);
-  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, 0, false, true, kO>>(p, stream);
+  if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, false, true, kO | kRegBands>>(p, stream);
+  return launch_dealt_cfg<Cfg<R3, 1, true, false, false, false, false, 1, false, true, kO>>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,8 +410,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   // Welch (hop = N/2) streams when the epochs are dense (see sense_kernel)
   const bool welch = C::WIN && p.frame_stride * 2 == G::N;
   const bool welch_stream = welch && p.epoch_stride == (long long)p.K * (G::N / 2);
-  const bool multi = (C::OPT & kSpread) != 0 && (C::OPT & kMulti) != 0 && C::ABL == 0 && C::PREFETCH &&
-                     (!welch || welch_stream);
+  const bool multi = (C::OPT & kMulti) != 0 && C::PREFETCH && (!welch || welch_stream);
   SenseParams q = p;
   unsigned grid;
   if (multi) {
@@ -517,7 +424,7 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
     q.tail_groups_per_wg = 1;
     grid = (unsigned)n_groups;
   }
-  const size_t lds = ((size_t)G::GROUPS * C::NBUF * Lay<C>::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
+  const size_t lds = ((size_t)G::GROUPS * C::NBUF * G::GROUP_CPLX + 16 * C::R3) * sizeof(cx) + kCloseLdsBytes;
   if (grid == 0) return hipSuccess;
   auto kfn = sense_kernel<C>;
   if (lds > 48 * 1024) {
@@ -533,9 +440,15 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
 // (crn_api.cpp) when no per-bin spectrum is stored.
 static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
 
-// Default configuration of every size: all mode / window / short-frame combinations.
+// The forms every size has, by mode / window / packet length / close.  What is specialised is what BASELINE.json's configurations and
+// the engine run: whole frames (FULL: no zero-padding mask) where the band plan is the reference's (kRows | kRegBands) or a small one in
+// energy mode (kRegBands); everything else — table windows, |X| mode with another plan or a spectrum request, short packets with a
+// small custom plan — runs ONE form that masks at run time (and closes through the LDS walk where the register close has no form).
+//   WHICH        0 all, 1 unwindowed kernels only, 2 windowed only
+//   PRUNE        the reference-plan forms exist (not in the wire-format unit)
+//   ENERGY_FULL  the unwindowed energy-mode whole-frame forms belong to this call (false at N = 4096: launch_rn has them)
 template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = kSpread | kLdsBlk | kPrioValu | kMulti,
-          int WHICH = 0 /* 0 all, 1 unwindowed kernels only, 2 windowed only */, bool PRUNE = true>
+          int WHICH = 0, bool PRUNE = true, bool ENERGY_FULL = true>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
   const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
@@ -543,41 +456,34 @@ static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipSt
   // keep only those registers: 7 of 16 at N = 512 (where the reference's |X| costs a square root per bin and frame), 12 / 11 / 7 at
   // 1024 / 2048 / 4096
   [[maybe_unused]] const bool prune = PRUNE && regb && ref_acc_mask(R3) != 0xFFFFu && (p.acc_mask & ~ref_acc_mask(R3)) == 0;
-#define CRN_GO(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT>>(p, stream)
-#define CRN_GO_R(MAGV, WINV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands>>(p, stream)
-  if constexpr (WHICH != 1) {
-    if (mag && win) { if (full) CRN_GO(true, true, true); else CRN_GO(true, true, false); }
-    if (win) { if (full) CRN_GO(false, true, true); else CRN_GO(false, true, false); }
-  }
-  if constexpr (WHICH != 2 && PRUNE) {
-#define CRN_GO_RP(MAGV, FULLV) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, false, TW2LDS, OCC, 0, FULLV, PK, OPT | kRegBands | kRows>>(p, stream)
-    if (prune) {
-      if (mag) { if (full) CRN_GO_RP(true, true); else CRN_GO_RP(true, false); }
-      if (full) CRN_GO_RP(false, true);
-      CRN_GO_RP(false, false);
-    }
-#undef CRN_GO_RP
+#define CRN_GO(MAGV, WINV, FULLV, EXTRA) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, FULLV, PK, OPT | (EXTRA)>>(p, stream)
+  if constexpr (WHICH != 1) {   // table windows: one form per mode
+    if (win) { if (mag) CRN_GO(true, true, false, 0); else CRN_GO(false, true, false, 0); }
   }
   if constexpr (WHICH != 2) {
-    if (regb) {
-      if (mag) { if (full) CRN_GO_R(true, false, true); else CRN_GO_R(true, false, false); }
-      if (full) CRN_GO_R(false, false, true);
-      CRN_GO_R(false, false, false);
+    if constexpr (PRUNE) {      // the reference channel plan: |X| and energy, whole frames and short packets
+      if (prune) {
+        if (mag) { if (full) CRN_GO(true, false, true, kRegBands | kRows); else CRN_GO(true, false, false, kRegBands | kRows); }
+        if constexpr (ENERGY_FULL) { if (full) CRN_GO(false, false, true, kRegBands | kRows); }
+        if (!full) CRN_GO(false, false, false, kRegBands | kRows);
+      }
     }
-    if (mag) { if (full) CRN_GO(true, false, true); else CRN_GO(true, false, false); }
-    if (full) CRN_GO(false, false, true);
-    CRN_GO(false, false, false);
+    if (regb) {                 // another small plan: register close for |X| (any packet length) and for energy on whole frames
+      if (mag) CRN_GO(true, false, false, kRegBands);
+      if constexpr (ENERGY_FULL) { if (full) CRN_GO(false, false, true, kRegBands); }
+    }
+    if (mag) CRN_GO(true, false, false, 0);   // any plan, spectrum requests: the LDS walk
+    if constexpr (ENERGY_FULL) { if (full) CRN_GO(false, false, true, 0); }
+    if (!full) CRN_GO(false, false, false, 0);
   }
   return hipErrorInvalidValue;
 #undef CRN_GO
-#undef CRN_GO_R
 }
 
-// The plain 4096-point kernel's forms (energy mode, no window, L = N) — the default, its unpruned form, the all-twiddles-in-
-// registers form — and, in the A/B build, the measurement variants.
-template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, int ABL, bool PK, int OPT = 0>
+// The plain 4096-point kernel's forms (energy mode, no window, L = N): the default and its unpruned form.
+template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool PK, int OPT = 0>
 static hipError_t launch_rn(const SenseParams &p, bool, bool, hipStream_t stream) {
-  return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, false, false, TW2LDS, OCC, ABL, true, PK, OPT>>(p, stream);
+  return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, false, false, TW2LDS, OCC, true, PK, OPT>>(p, stream);
 }
 
 

@@ -15,7 +15,8 @@ and both statements consist of v_pk_{add,mul,fma}_f32 only (or the first is one 
 own s_waitcnt lgkmcnt(0)).  Every other s_nop — the ones real hazards need (readlane after a VALU
 write, DPP sources, trans results, ...) — has a compiler-generated instruction on at least one side and is left alone.
 
-  strip_asm_nops.py in.s out.s     prints how many were dropped
+  strip_asm_nops.py in.s out.s     prints how many were dropped; exit 2 (and no output file) when the input does not look like what this
+                                   filter was written for: no `;;#ASMSTART` / `;;#ASMEND` markers at all, or markers that do not pair up
 """
 import re
 import sys
@@ -40,8 +41,18 @@ def lds_read_block(block):
     return len(body) > 1 and all(LDS_READ.match(ln) for ln in body) and body[-1].strip() == "s_waitcnt lgkmcnt(0)"
 
 
+class NotWhatWasExpected(Exception):
+    pass
+
+
 def main(src, dst):
     lines = open(src).read().split("\n")
+    starts = sum(1 for ln in lines if ln.strip() == ";;#ASMSTART")
+    ends = sum(1 for ln in lines if ln.strip() == ";;#ASMEND")
+    if starts == 0:
+        raise NotWhatWasExpected("no ;;#ASMSTART markers in the assembly: the compiler's output format changed (or the unit has no inline asm)")
+    if starts != ends:
+        raise NotWhatWasExpected(f"{starts} ;;#ASMSTART but {ends} ;;#ASMEND markers")
     out, dropped, kept = [], 0, 0
     i, n = 0, len(lines)
     last_asm_pk = False          # the previous inline-asm statement was packed-f32 only and nothing but comments followed it
@@ -51,6 +62,8 @@ def main(src, dst):
         if s == ";;#ASMSTART":
             j = i + 1
             while lines[j].strip() != ";;#ASMEND":
+                if lines[j].strip() == ";;#ASMSTART":
+                    raise NotWhatWasExpected(f"nested ;;#ASMSTART at line {j + 1}")
                 j += 1
             block = lines[i + 1:j]
             out.extend(lines[i:j + 1])
@@ -80,4 +93,8 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    try:
+        main(sys.argv[1], sys.argv[2])
+    except NotWhatWasExpected as e:
+        print(f"strip_asm_nops: REFUSED: {e}")
+        sys.exit(2)

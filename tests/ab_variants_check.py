@@ -24,7 +24,16 @@ def per_bin_err(spec, floor=1e-2):
 
 
 base = None
-for v in list(range(0, 11)) + [13, 23, 24]:      # 11, 12, 14-18: ablations / trace build, not sensing results
+REMOVED = [1, 3, 4, 5, 6, 8, 9, 10, 11, 12, 14, 15, 16, 18, 23, 24, 25]   # round 5: docs/history/removed_variants.md
+for v in REMOVED:                                # refused by the measurement build too
+    s = cs.Sensor(cfg)
+    try:
+        s.set_variant(v)
+        raise SystemExit(f"variant {v} was removed but crn_sense_set_variant accepts it")
+    except cs.CrnError:
+        pass
+    s.close()
+for v in [0, 2, 7, 13]:                      # 17: the trace build, not a sensing result
     s = cs.Sensor(cfg)
     s.set_variant(v)
     got = s.run_host(iq, n_epochs, want_spectrum=True)
@@ -41,7 +50,7 @@ for b in range(64):
     wcfg.thresh[b] = 4.0 * 64 * 4096 * 1e-6 * 0.375
 wiq, _ = signals.make_epochs(wcfg, 6, seed=78)
 wbase = None
-for v in (0, 19, 20, 21, 22, 25, 26, 27):    # the windowed kernel's A/B set (25-27: the LDS-traffic forms; their spectrum path too)
+for v in (0, 19, 20, 21, 22, 26, 27):    # the windowed kernel's A/B set (26, 27: twiddles in registers; their spectrum path too)
     s = cs.Sensor(wcfg)
     s.set_variant(v)
     got = s.run_host(wiq, 6)
@@ -54,7 +63,7 @@ for v in (0, 19, 20, 21, 22, 25, 26, 27):    # the windowed kernel's A/B set (25
 # ... and with a per-bin spectrum asked for (the LDS form of the close instead of the aligned-band one)
 sbase = None
 wtruth_cfg = wcfg
-for v in (0, 25, 26, 27):
+for v in (0, 26, 27):
     s = cs.Sensor(wcfg)
     s.set_variant(v)
     got = s.run_host(wiq, 6, want_spectrum=True)

@@ -41,11 +41,12 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipS
   g_launches++;
   return hipSuccess;
 }
-int sense_num_variants() { return 24; }
+int sense_num_variants() { return 27; }
 hipError_t launch_nop(hipStream_t) { return hipSuccess; }
-int sense_deal_rounds(int, bool, int) { return 0; }
+int sense_deal_rounds(int, bool, bool, bool, int, size_t) { return 0; }
 unsigned sense_ref_acc_mask(int) { return 0xFFFFu; }
 bool sense_variant_available(int v) { return v == 0; }
+bool sense_variant_traces(int) { return false; }
 void sense_variant(int, int, int *a, int *b, int *c, int *d, int *e) { *a = *b = *c = *e = 1; *d = 0; }
 void sense_geometry(int fft_len, int, int *t, int *l, int *e) { *t = 256; *l = 0; *e = 256 / (fft_len / 16); }
 hipError_t launch_fft(const FftParams &, int, hipStream_t) { return hipSuccess; }

@@ -60,18 +60,22 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, i
   g_launches++;
   return hipSuccess;
 }
-int sense_num_variants() { return 24; }
+int sense_num_variants() { return 27; }
 hipError_t launch_nop(hipStream_t) { return hipSuccess; }
-// (the rule of csrc/crn_kernels.hip restated: frames of 512 / 1024 points, K >= 2, the frame slots within 160 KiB of LDS)
-int sense_deal_rounds(int fft_len, bool mag, int K) {
+// (the rule of csrc/crn_kernels.hip restated: frames of 512 / 1024 points, K >= 2, the frame slots within the device's LDS per workgroup)
+size_t g_last_lds_budget = 0;
+int sense_deal_rounds(int fft_len, bool mag, bool win, bool hann_whole, int K, size_t lds_budget) {
+  g_last_lds_budget = lds_budget;
+  if (win && (mag || !hann_whole)) return 0;
   if ((fft_len != 512 && fft_len != 1024) || K < 2) return 0;
   const int groups = 256 / (fft_len / 16), rounds = (K + groups - 1) / groups;
   const size_t fixed = fft_len == 512 ? 8 * 16 * 34 * 8 + 32 * 8 + 3136 : 4 * 16 * 68 * 8 + 64 * 8 + 3136;
-  return fixed + (size_t)rounds * groups * fft_len * (mag ? 4 : 8) <= 160 * 1024 ? rounds : 0;
+  return fixed + (size_t)rounds * groups * fft_len * (mag ? 4 : 8) <= lds_budget ? rounds : 0;
 }
 // the masks csrc/crn_butterflies.h derives from the reference channel plan (ref_acc_mask): restated here from the plan itself, below
 unsigned sense_ref_acc_mask(int fft_len) { return fft_len == 512 ? 0x85e1u : fft_len == 1024 ? 0xbf73u : fft_len == 2048 ? 0x9f9bu : 0x8267u; }
-bool sense_variant_available(int v) { return v == 0 || v == 13 || v == 2 || v == 23; }   // the shipped library's set
+bool sense_variant_available(int v) { return v == 0 || v == 13 || v == 2; }   // the shipped library's set
+bool sense_variant_traces(int) { return false; }
 void sense_variant(int, int, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) { *nbuf = 1; *prefetch = 1; *nt = 1; *tw2lds = 0; *pk = 1; }
 void sense_geometry(int fft_len, int, int *threads, int *lds_bytes, int *epochs_per_block) { *threads = 256; *lds_bytes = 0; *epochs_per_block = 256 / (fft_len / 16); }
 hipError_t launch_fft(const FftParams &p, int fft_len, hipStream_t) { g_fft = p; g_fft_len = fft_len; return hipSuccess; }
@@ -267,7 +271,7 @@ static void test_geometry() {
           check_coverage(p, N, "plain");
           // the dealt-frame form: launches of up to one epoch per compute unit, 512 / 1024 points, at least two frames
           const int groups = 256 / (N / 16);
-          const int fits = crn::sense_deal_rounds(N, false, K);   // 0 when the K frame slots do not fit in LDS (K = 32 here)
+          const int fits = crn::sense_deal_rounds(N, false, false, false, K, 160 * 1024);   // 0 when the K frame slots do not fit in LDS (K = 32 here)
           REQUIRE(fits == 0 || fits == (K + groups - 1) / groups);
           REQUIRE((fits > 0) == ((N == 512 || N == 1024) && K >= 2 && K <= 10));
           const bool want_deal = fits > 0 && E <= (long long)n_cus;
@@ -344,7 +348,8 @@ static void test_arguments_and_counters() {
   REQUIRE(st.launches == 1 && st.epochs == 12 && st.samples == 12 * 3640);
   // the shipped variant policy
   REQUIRE(crn_sense_set_variant(h, 7) == CRN_ERR_ARG && std::strstr(crn_last_error(), "measurement variant") != nullptr);
-  REQUIRE(crn_sense_set_variant(h, 23) == CRN_OK && crn_sense_set_variant(h, 0) == CRN_OK);
+  REQUIRE(crn_sense_set_variant(h, 2) == CRN_OK && crn_sense_set_variant(h, 13) == CRN_OK && crn_sense_set_variant(h, 0) == CRN_OK);
+  REQUIRE(crn_sense_set_variant(h, 23) == CRN_ERR_ARG);   // (removed in round 5)
   REQUIRE(crn_sense_set_variant(h, 403) == CRN_ERR_ARG && crn_sense_set_variant(h, -1) == CRN_ERR_ARG);
   {
     int64_t n = -1;

@@ -13,7 +13,7 @@
 #include <thread>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorNotSupported = 801 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 struct fake_hip_stream { int unused; };
@@ -70,10 +70,21 @@ inline hipError_t hipEventSynchronize(hipEvent_t e) {
 struct float2 { float x, y; };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n); }
-enum { hipDeviceAttributeMultiprocessorCount = 63 };
+enum { hipDeviceAttributeMultiprocessorCount = 63, hipDeviceAttributeMaxSharedMemoryPerBlock = 74 };
 inline int g_fake_hip_cus = 256;
+inline int g_fake_hip_lds_bytes = 160 * 1024;   // gfx950; a test may shrink it (a device or partition with 64 KiB)
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipDeviceGetAttribute(int *v, int attr, int) { *v = attr == hipDeviceAttributeMultiprocessorCount ? g_fake_hip_cus : 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int *v, int attr, int) {
+  *v = attr == hipDeviceAttributeMultiprocessorCount ? g_fake_hip_cus : attr == hipDeviceAttributeMaxSharedMemoryPerBlock ? g_fake_hip_lds_bytes : 0;
+  return hipSuccess;
+}
+// stream capture: a test marks a stream as capturing (crn_api.cpp refuses updates on it)
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+inline std::atomic<void *> g_fake_hip_capturing_stream{nullptr};
+inline hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus *st) {
+  *st = (s != nullptr && (void *)s == g_fake_hip_capturing_stream.load()) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+  return hipSuccess;
+}
 inline hipError_t hipRuntimeGetVersion(int *v) { *v = HIP_VERSION; return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { fake_hip_note(true); std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }

@@ -110,6 +110,11 @@ int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epoc
   }
   return CRN_OK;
 }
+// what the ring calls (csrc/crn_ingest.cpp): either sample format
+int crn_sense_run_device_any(crn_handle *h, const void *d_iq, int32_t bytes_per_sample, int64_t n_epochs, int32_t L, int64_t stride, const crn_out *o, void *st) {
+  return bytes_per_sample == 4 ? crn_sense_run_device_sc16(h, static_cast<const int16_t *>(d_iq), n_epochs, L, stride, o, st)
+                               : crn_sense_run_device(h, static_cast<const float *>(d_iq), n_epochs, L, stride, o, st);
+}
 }
 
 #endif

@@ -39,7 +39,7 @@ for seed in range(first, first + n_seeds):
         cfg.decide = int(rng.choice([1, 1, 2]))
         if rng.random() < 0.7:
             cfg.window, cfg.mode, L = 1, 1, n
-    variant = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 8, 9, 10])) if n == 4096 else 0
+    variant = int(rng.choice([0, 0, 0, 2, 7])) if n == 4096 else 0
     if cfg.window == 1 and cfg.mode == 1 and L == n and rng.random() < 0.5:
         variant = int(rng.choice([19, 20, 21, 22]))   # A/B set of the windowed kernel
     want_spec = bool(rng.random() < 0.5)
@@ -124,7 +124,7 @@ for seed in range(first, first + n_seeds):
         fl = raw.astype(np.float32) / np.float32(32768.0)
         d_raw, d_fl = torch.from_numpy(raw).cuda(), torch.from_numpy(fl).cuda()
         outs2 = []
-        for sc in (False, True):
+        for sc in ((False, True) if cs.has_sc16() else (False,)):   # wire format: only a library built with make SC16=1
             f_ = torch.zeros(n_epochs, cfg.n_bands, device="cuda")
             o_ = torch.zeros(n_epochs, cfg.n_bands, dtype=torch.uint8, device="cuda")
             d_ = torch.zeros(n_epochs, dtype=torch.int32, device="cuda")

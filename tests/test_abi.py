@@ -3,6 +3,7 @@ and fails loudly (no CPU fallback) when asked to compute without a device."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -11,14 +12,30 @@ import crnsense as cs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(text):
+    return set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", text))
+
+
 def test_header_symbols_are_exported(built):
+    """libcrnsense.so exports exactly what include/crn_sense.h declares unconditionally; the block behind CRN_WITH_SC16 (the optional
+    wire-format input) is exported by a `make SC16=1` library — all five or none — and by nothing else."""
     hdr = open(os.path.join(ROOT, "include", "crn_sense.h")).read()
-    declared = set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", hdr))
+    a, b = hdr.index("#ifdef CRN_WITH_SC16"), hdr.index("#endif /* CRN_WITH_SC16 */")
+    optional, declared = _declared(hdr[a:b]), _declared(hdr[:a] + hdr[b:])
     assert declared == set(cs.EXPORTS), declared ^ set(cs.EXPORTS)
+    assert optional == set(cs.SC16_EXPORTS), optional ^ set(cs.SC16_EXPORTS)
     L = cs.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert L.crn_abi_version() == cs.CRN_ABI_VERSION
+    out = subprocess.run(["nm", "-D", "--defined-only", cs.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    if not os.environ.get("CRN_SENSE_LIB"):
+        assert exported == declared, exported ^ declared        # nothing undeclared leaks out of the product, nothing optional is in it
+    for path in (cs.SC16_LIB_PATH, cs.PLAIN_LIB_PATH):          # the optional build and the test artefact: the product + the five
+        if os.path.exists(path):
+            out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+            assert {ln.split()[-1] for ln in out.splitlines() if " T " in ln} == declared | optional, path
 
 
 def test_engine_directory_is_self_contained(built):

@@ -115,7 +115,10 @@ def test_bench_ranks_stop_together_when_rccl_cannot_be_loaded(built):
 
 def test_bench_wire_format_mode(built):
     """--wire-format: samples held as int16 pairs; the oracle check of the run still applies (it compares against the float samples the
-    wire buffer was packed from), bytes per step are 4 per sample, and the workload says it is not the headline configuration."""
+    wire buffer was packed from), bytes per step are 4 per sample, and the workload says it is not the headline configuration.
+    (bench.py loads the optional libcrnsense_sc16.so for it.)"""
+    if not os.path.exists(os.path.join(ROOT, "cognitive-radio-network_amd", "libcrnsense_sc16.so")):
+        pytest.skip("libcrnsense_sc16.so was not built (make -C csrc SC16=1)")
     d = _run("--cpu-epochs", "0", "--wire-format")
     assert d["config"]["bytes_per_gpu_per_step"] == 512 * 40960 * 4
     assert "NOT THE HEADLINE CONFIGURATION" in d["config"]["workload"] and d["roofline"]["traffic"] is None   # (--no-live-traffic here)

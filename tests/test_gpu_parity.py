@@ -132,22 +132,18 @@ def test_per_bin_error_against_in_band_snr(built):
     """the per-bin tolerance stated precisely instead of switched by size.  Idle epochs and driven epochs
     apart; the driven channel's in-band SNR swept from 0 to +36 dB (carrier power / noise power inside the channel's bins; the
     headline generator's rms 0.02 is +38 dB at N = 4096); every size; the kernel that answers a spectrum request (all 16 pass-3
-    rows, pass-1 twiddles in their compressed form at N = 4096) and, at 4096, the form with every twiddle read as stored
-    (variant 23).  Asserted: 1e-5 at the stated floor wherever STATED_BAR_HOLDS_UP_TO_DB says so, the fitted line above, and at
+    rows, pass-1 twiddles in their compressed form at N = 4096).  Asserted: 1e-5 at the stated floor wherever STATED_BAR_HOLDS_UP_TO_DB says so, the fitted line above, and at
     floor 1e-2 everywhere; never worse than the radix-2 restatement."""
     import os
     sigma2 = 1e-6
-    lines = ["N  snr_dB  rms        gpu@1e-3   gpu@1e-2   oracle@1e-3  [v23@1e-3]   bound@1e-3   "
+    lines = ["N  snr_dB  rms        gpu@1e-3   gpu@1e-2   oracle@1e-3  bound@1e-3   "
              "(max over bins and epochs of |E - E64| / max(E64, floor * mean E64); energy mode, K = 10, rectangular)"]
     fails = []
     for n in (512, 1024, 2048, 4096):
         cfg = cs.cfg_energy_scaled(n, 4.0)
         sensors = [cs.Sensor(cfg)]
-        if n == 4096:
-            sensors.append(cs.Sensor(cfg))
-            sensors[1].set_variant(23)
         for snr in SNR_SWEEP_DB:
-            worst = {"g3": 0.0, "g2": 0.0, "o3": 0.0, "v3": 0.0}
+            worst = {"g3": 0.0, "g2": 0.0, "o3": 0.0}
             rms_used = 0.0
             for ch in (1, 2, 3):
                 bins = signals.band_bins(cfg, ch).size
@@ -162,14 +158,11 @@ def test_per_bin_error_against_in_band_snr(built):
                 worst["g3"] = max(worst["g3"], per_bin_err(got["spectrum"], truth, 1e-3))
                 worst["g2"] = max(worst["g2"], per_bin_err(got["spectrum"], truth, 1e-2))
                 worst["o3"] = max(worst["o3"], per_bin_err(want["spectrum"], truth, 1e-3))
-                if len(sensors) > 1:
-                    worst["v3"] = max(worst["v3"], per_bin_err(sensors[1].run_host(iq, n_epochs, want_spectrum=True)["spectrum"], truth, 1e-3))
                 if snr is None:
                     break     # idle epochs do not depend on the channel
             bound = snr_bound(n, snr)
             tag = "idle" if snr is None else f"{snr:+d}"
-            lines.append(f"{n:5d} {tag:>5s}  {rms_used:.3e}  {worst['g3']:.3e}  {worst['g2']:.3e}  {worst['o3']:.3e}   "
-                         + (f"{worst['v3']:.3e}" if len(sensors) > 1 else "    -    ") + f"   {bound:.2e}")
+            lines.append(f"{n:5d} {tag:>5s}  {rms_used:.3e}  {worst['g3']:.3e}  {worst['g2']:.3e}  {worst['o3']:.3e}   {bound:.2e}")
             if not (worst["g3"] < bound):
                 fails.append(lines[-1] + "   <- above the bound at the stated floor")
             if not (worst["g2"] < PER_BIN_TOL):
@@ -328,15 +321,15 @@ def test_kernel_variants_agree(built):
 
 
 def test_shipped_library_carries_no_measurement_variants(built):
-    """crn_sense_set_variant in libcrnsense.so: the default (0 = 13), its unpruned form (2) and the all-twiddles-in-registers form
-    (23) — all of which are sensing results, checked against the default here — and nothing else: the ablations and the trace build
-    (which writes clock stamps over the caller's ann_out buffer) are refused, not shipped."""
+    """crn_sense_set_variant in libcrnsense.so: the default (0 = 13) and its unpruned form (2) — both sensing results, checked against
+    each other here — and nothing else: the measurement forms of libcrnsense_ab.so (among them the trace build, which writes clock
+    stamps over the caller's ann_out buffer) and the numbers of forms that no longer exist are refused."""
     cfg = cs.cfg_energy_scaled(4096, 4.0)
     n_epochs = 9
     iq, _ = signals.make_epochs(cfg, n_epochs, seed=77)
     truth = signals.spectrum_f64(cfg, iq, n_epochs)
     base = None
-    for v in (0, 13, 2, 23):
+    for v in (0, 13, 2):
         s = cs.Sensor(cfg)
         s.set_variant(v)
         got = s.run_host(iq, n_epochs)                      # (no spectrum: the default then runs its row-pruned, register-close form)
@@ -347,7 +340,7 @@ def test_shipped_library_carries_no_measurement_variants(built):
         assert np.allclose(got["features"], base["features"], rtol=2e-6, atol=0), v
         assert np.array_equal(got["occupancy"], base["occupancy"]), v
     s = cs.Sensor(cfg)
-    for v in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24):
+    for v in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27):
         with pytest.raises(cs.CrnError, match="measurement variant"):
             s.set_variant(v)
     s.set_variant(100 + 2)       # launch geometry overrides stay (they select no other kernel)

@@ -3,6 +3,9 @@ USRPs put on the network, src/extensible_cognitive_radio.cpp:1263-1265): the ker
 converter does (int16 / 32768), so every output must be BIT-IDENTICAL to the float path on the converted samples — and through it
 equal to the oracle within the float path's own tolerance."""
 import ctypes as C
+import os
+import subprocess
+import sys
 import zlib
 
 import numpy as np
@@ -11,7 +14,48 @@ import pytest
 import crnsense as cs
 import oracle_py as orc
 
+# The wire-format kernels and their five entry points are OPTIONAL (make -C csrc SC16=1 -> libcrnsense_sc16.so): the default library does
+# not carry them.  The tests of this file run when the loaded library has them ($CRN_SENSE_LIB=.../libcrnsense_sc16.so) and skip
+# otherwise; test_wire_format_suite_on_the_optional_library runs them that way in a child process whenever that library was built.
+HAVE = cs.has_sc16()
+needs_sc16 = pytest.mark.skipif(not HAVE, reason="the loaded library was built without the optional wire-format kernels (make SC16=1)")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _child_suite(marker):
+    if HAVE:
+        pytest.skip("already running against a library with the wire-format kernels")
+    if not os.path.exists(cs.SC16_LIB_PATH):
+        pytest.skip("libcrnsense_sc16.so was not built (make -C csrc SC16=1)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", marker, "-k", "not optional_library and not default_library", "-p", "no:cacheprovider", os.path.abspath(__file__),
+                        os.path.join(ROOT, "tests", "test_dealt_frames.py") + "::test_dealt_frames_in_the_wire_format"],
+                       cwd=ROOT, env=dict(os.environ, CRN_SENSE_LIB=cs.SC16_LIB_PATH), capture_output=True, text=True, timeout=1500)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and " passed" in tail and "skipped" not in tail, r.stdout[-3000:] + r.stderr[-2000:]
+    return tail
+
+
+def test_default_library_has_no_wire_format_entry_points(built):
+    """... and says so: the binding raises instead of calling into nothing, and the library itself answers a wire-format launch
+    (which only an internal caller could request) with an error, not a crash."""
+    if HAVE:
+        pytest.skip("running against a library with the wire-format kernels")
+    L = cs.lib()
+    assert not any(hasattr(L, name) for name in cs.SC16_EXPORTS)
+    with pytest.raises(cs.CrnError, match="SC16=1"):
+        cs._need_sc16("x")
+
+
+def test_wire_format_host_checks_on_the_optional_library(built):
+    print(_child_suite("not gpu"))
+
+
+@pytest.mark.gpu
+def test_wire_format_suite_on_the_optional_library(built):
+    print(_child_suite("gpu"))
+
+
+@needs_sc16
 def test_sc16_argument_errors(built):
     L = cs.lib()
     o = cs.Out()
@@ -48,6 +92,7 @@ def _cfgs():
     yield "hann2048_L1500", c, 1500
 
 
+@needs_sc16
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,cfg,L", list(_cfgs()), ids=[n for n, _, _ in _cfgs()])
 @pytest.mark.parametrize("want_spectrum", [False, True], ids=["", "spectrum"])
@@ -94,6 +139,7 @@ def test_wire_format_is_bit_identical_to_the_float_path(built, name, cfg, L, wan
     s.close()
 
 
+@needs_sc16
 @pytest.mark.gpu
 def test_wire_format_argument_checks(built):
     import torch
@@ -107,6 +153,7 @@ def test_wire_format_argument_checks(built):
     s.close()
 
 
+@needs_sc16
 @pytest.mark.gpu
 def test_wire_format_ring_matches_the_float_ring(built):
     """The ingest ring fed int16 packets (crn_ingest_create_sc16 / crn_ingest_push_sc16) against the ring fed the same samples as
@@ -138,6 +185,7 @@ def test_wire_format_ring_matches_the_float_ring(built):
     assert got[True] == got[False]
 
 
+@needs_sc16
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["ref512_L364", "energy4096", "welch1024"])
 def test_wire_format_with_another_converter_constant(built, mode):

@@ -7,8 +7,8 @@ import sys
 
 path = sys.argv[1] if len(sys.argv) > 1 else "cognitive-radio-network_amd/csrc/build/resource_usage.txt"
 txt = open(path).read()
-FLAGS = {2: 'Pair', 4: 'Spread', 32: 'LdsBlk', 64: 'Tw1C', 128: 'Fence', 256: 'Rows', 512: 'Multi', 1024: 'Prio', 2048: 'NoClose', 262144: 'RowsRT', 524288: 'X2Wide',
-         4096: 'Trace', 8192: 'RegB', 16384: 'HannSym', 32768: 'Tw2E', 65536: 'Aligned', 131072: 'Sc16', 1048576: 'Deal'}
+FLAGS = {4: 'Spread', 32: 'LdsBlk', 64: 'Tw1C', 256: 'Rows', 512: 'Multi', 1024: 'Prio', 4096: 'Trace', 8192: 'RegB', 16384: 'HannSym', 32768: 'Tw2E',
+         65536: 'Aligned', 131072: 'Sc16', 1048576: 'Deal'}   # csrc/crn_frame.h (kTrace: crn_frame_ab.h)
 K_V, K_S, K_X, K_O = "VGPRs", "SGPRs", r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
 bad = 0
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
@@ -23,8 +23,8 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     opt = int(a[-1])
     fl = '|'.join(v for k, v in FLAGS.items() if opt & k)
     v, s_, x, o = g(K_V), g(K_S), g(K_X), g(K_O)
-    want_occ = int(a[7])
+    want_occ = 1 if 'sense_kernel_dealt' in dem else int(a[7])   # (the dealt-frame kernel is launch_bounds(256, 1))
     flag = "" if (x == '0' and int(o) >= want_occ) else "   <-- scratch or occupancy below the launch bound"
     bad += bool(flag)
-    print(f"R3={a[0]:>2} MAG={a[4][0]} WIN={a[5][0]} TW2LDS={a[6][0]} OCC={a[7]} ABL={a[8]} FULL={a[9][0]} {fl:48s} VGPR {v:>3} SGPR {s_:>3} scratch {x:>3} occ {o}{flag}")
+    print(f"R3={a[0]:>2} MAG={a[4][0]} WIN={a[5][0]} TW2LDS={a[6][0]} OCC={a[7]} FULL={a[8][0]} {fl:48s} VGPR {v:>3} SGPR {s_:>3} scratch {x:>3} occ {o}{flag}")
 print(f"{bad} kernels with scratch or short of their occupancy")

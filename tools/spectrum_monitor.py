@@ -20,6 +20,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cognitive-radio-network_amd"))
+if "--sc16" in sys.argv and "CRN_SENSE_LIB" not in os.environ:
+    # captures of int16 pairs need the optional wire-format kernels: libcrnsense_sc16.so (make -C csrc SC16=1), chosen before the binding loads
+    os.environ["CRN_SENSE_LIB"] = os.path.join(ROOT, "cognitive-radio-network_amd", "libcrnsense_sc16.so")
 import crnsense as cs  # noqa: E402
 
 
