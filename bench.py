@@ -33,7 +33,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 kernel any other band table / a spectrum request gets (no row pruning)
   cpu_baseline  the oracle (CPU restatement of the reference path, built -O2 -march=native on this box)
                 timed on this box's host cores on a bounded sample of the same data: the threads the process may run at once (`value`)
-                and one thread — the reference's own topology — median of 3 passes of >= 3 s each
+                and one thread — the reference's own topology — BASELINE.md §3's protocol: 2 warm-up passes, median of 10.  At N > 1
+                rank 0 measures it after the timed region while the other ranks wait, so every 1 / 2 / 4 / 8-GPU line carries it.
+
+N > 1 is fail-fast: the gloo control plane and a per-stage watchdog on every rank share one limit (--stage-timeout, 300 s): a rank that
+dies or hangs — in gloo, inside RCCL, or waiting for the GPU — takes the job down with a non-zero exit within that time instead of
+holding the launcher until its own timeout.
 """
 import argparse
 import json
@@ -72,6 +77,33 @@ def usable_cores():
     except Exception:
         pass
     return n, why
+
+
+class Watchdog:
+    """N > 1 only: every rank must pass from one stage of the run to the next within `limit` seconds.  gloo's own timeout covers its
+    collectives; this covers what it cannot see — a rank stuck inside ncclCommInitRank, or in a device synchronise behind an
+    all-gather that a missing peer never completes.  On expiry the rank says where it was and exits 6 (os._exit: the main thread is
+    blocked in native code), which makes torch.distributed.run take the other ranks down."""
+
+    def __init__(self, limit, rank):
+        import threading
+        self.limit, self.rank, self.stage, self.t = float(limit), rank, "start", time.monotonic()
+        self.done = False
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def pet(self, stage):
+        self.stage, self.t = stage, time.monotonic()
+
+    def stop(self):
+        self.done = True
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(min(1.0, self.limit / 10))
+            if not self.done and time.monotonic() - self.t > self.limit:
+                print(f"bench.py: rank {self.rank}: stage '{self.stage}' did not finish within {self.limit:.0f} s (a peer hung or died?): "
+                      "exiting 6 so that the launcher stops the job", file=sys.stderr, flush=True)
+                os._exit(6)
 
 
 def self_launch(n):
@@ -209,6 +241,9 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 counter passes of a short child run (N = 1 only); "
                          "use the committed figure instead")
+    ap.add_argument("--stage-timeout", type=float, default=300.0,
+                    help="N > 1: seconds a rank may spend in one stage of the run (gloo collectives and the watchdog): a hung or dead "
+                         "peer ends the job with a non-zero exit within this time")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     ap.add_argument("--valu-json", default=os.path.join(ROOT, "profiles", "valu_counters.json"))
     args = ap.parse_args()
@@ -250,10 +285,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_collective
+    dog = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("gloo")   # control plane only; the data-path collective is crn_comm_* (RCCL)
+        dog = Watchdog(args.stage_timeout, rank)
+        # control plane only; the data-path collective is crn_comm_* (RCCL).  gloo's default timeout is 30 minutes — the driver's whole
+        # budget for a scaling run: one wedged rank must cost --stage-timeout, not the run
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.stage_timeout))
+
+    def stage(name):
+        if dog is not None:
+            dog.pet(name)
+    stage("set-up")
 
     if args.mode == "ref":
         cfg = cs.cfg_reference()
@@ -354,8 +399,10 @@ def main():
     # N > 1: the occupancy block alternates between two slots of the C ABI's communicator so that the
     # all-gather of step i (side stream) overlaps the sensing kernel of step i + 1
     # (two streams: four slots, so that a stream's next launch never waits for the gather of its previous one)
+    stage("communicator (ncclCommInitRank is collective)")
     ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world, depth=4 if two_streams else 2) if multi else (None, "")
     torch.cuda.synchronize()   # the set-up above ran on the current stream; the timed launches may run on others
+    stage("warm-up")
     n_done = 0
 
     def step(sn, epochs, ev=None):
@@ -390,6 +437,7 @@ def main():
     span0 = torch.cuda.Event(enable_timing=True)
     span1 = [torch.cuda.Event(enable_timing=True) for _ in tstreams]
 
+    stage("timed region")
     barrier()
     t0 = time.perf_counter()
     span0.record(tstreams[0])
@@ -425,6 +473,7 @@ def main():
     achieved = algo_bytes / (kern_ms_mean * 1e-3) / 1e9
 
     # ---- sanity on the timed outputs ----------------------------------------------------------------
+    stage("output checks")
     last = n_done - 1
     feats, occ, dec, ann = (sets[last % n_sets][k] for k in ("feats", "occ", "dec", "ann"))   # what the last timed launch wrote
     occ_host = ex.local_host(last) if ex is not None else occ.cpu().numpy()
@@ -484,8 +533,8 @@ def main():
         tj = committed(args.traffic_json, mode_key)
         if tj:  # measured once per kernel with rocprofv3 PMC passes of this command; scales linearly with the batch
             traffic = int(tj["hbm_bytes_per_launch"] * (E / tj["epochs"]))
-            traffic_source = (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this "
-                              "command (committed), scaled by the batch")
+            traffic_source = (f"committed ({os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this "
+                              "command at N = 1), scaled by the batch" + (", not re-measured at N > 1" if world > 1 else ""))
 
     # ---- second roofline for the windowed kernels: VALU ---------------------------------------------
     roofline_valu = None
@@ -585,8 +634,13 @@ def main():
         s2.close()
 
     # ---- CPU baseline ---------------------------------------------------------------------------------
+    # north_star: "throughput is reported at 1/2/4/8 GPUs next to the liquid-dsp CPU path timed on the same box's host cores (count
+    # stated)" — so at every N: rank 0 measures after the timed region, the other ranks wait at the barrier below (idle: the host cores
+    # are rank 0's).  Protocol = BASELINE.md §3: 2 warm-up passes, median of 10 timed passes; topology A = one thread (the reference's
+    # single CE pthread, src/extensible_cognitive_radio.cpp:1761-1808), topology B = the threads this process may run at once.
+    stage("cpu baseline (rank 0 measures, the others wait)")
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_epochs != 0:
+    if rank == 0 and args.cpu_epochs != 0:
         import oracle_py as orc
         native = orc.use_native_build()       # -O2 -march=native, compiled on this box (the portable build otherwise)
         hw = os.cpu_count() or 1
@@ -594,16 +648,20 @@ def main():
         cap = max(1, (7168 * 40960) // spe)   # at most 2.2 GiB of the batch goes to the host
         n_all = args.cpu_epochs if args.cpu_epochs > 0 else min(E, cap)
         host_iq = iq[: cs.samples_needed(cfg, n_all) * 2].cpu().numpy()
-        quick = args.cpu_epochs > 0           # explicit sample size: one pass each (tests)
+        quick = args.cpu_epochs > 0           # explicit sample size: one warm-up, two passes (tests)
+        n_warm, n_pass = (1, 2) if quick else (2, 10)
 
         def timed(n_ep, threads, min_s):
-            orc.run(cfg, host_iq, min(n_ep, 2 * threads), n_threads=threads)  # warm-up (page in, plan)
+            """(median rate, rates, repetitions per pass, last outputs): n_warm untimed passes, then n_pass timed ones of >= min_s each."""
             t1 = time.perf_counter()
-            orc.run(cfg, host_iq, n_ep, n_threads=threads)
+            ref_out = orc.run(cfg, host_iq, n_ep, n_threads=threads)            # warm-up 1 (pages in the sample, sizes the passes)
             one = time.perf_counter() - t1
             reps = 1 if quick else max(1, int(math.ceil(min_s / max(one, 1e-3))))
+            for _ in range(n_warm - 1):
+                for _ in range(reps):
+                    orc.run(cfg, host_iq, n_ep, n_threads=threads)
             rates = []
-            for _ in range(1 if quick else 3):
+            for _ in range(n_pass):
                 t1 = time.perf_counter()
                 for _ in range(reps):
                     ref_out = orc.run(cfg, host_iq, n_ep, n_threads=threads)
@@ -616,34 +674,39 @@ def main():
         # for a fraction of a second, tools/cpu_scaling.py).
         cores, sweep = quota, {}
         if not quick:
-            for th in sorted({c for c in (quota, 2 * quota, 4 * quota) if 1 <= c <= hw}):
+            for th in sorted({c for c in (2 * quota, 4 * quota) if 1 <= c <= hw}):
                 orc.run(cfg, host_iq, min(n_all, 2 * th), n_threads=th)
                 t1 = time.perf_counter()
                 done = 0
-                while time.perf_counter() - t1 < 2.0:
+                while time.perf_counter() - t1 < 1.0:
                     orc.run(cfg, host_iq, n_all, n_threads=th)
                     done += n_all
                 sweep[th] = done * spe / (time.perf_counter() - t1) / 1e6
-        all_rate, all_rates, all_reps, ref = timed(n_all, cores, 3.0)
-        n_one = n_all if quick else max(1, n_all // 4)   # ~0.6 s of one thread per repetition
-        one_rate, one_rates, one_reps, _ = timed(n_one, 1, 3.0)
+        all_rate, all_rates, all_reps, ref = timed(n_all, cores, 1.0)
+        n_one = n_all if quick else max(1, n_all // 4)   # ~0.6 s of one thread per pass
+        one_rate, one_rates, one_reps, _ = timed(n_one, 1, 0.5)
+        sweep[cores] = all_rate
         # the same sample doubles as a parity check of the timed GPU outputs
         g = feats[:n_all].cpu().numpy()
         rel = np.abs(g - ref["features"]) / np.maximum(np.abs(ref["features"]), 1e-30)
         if not args.no_check and (rel.max() > 1e-5 or not np.array_equal(occ_host[:n_all], ref["occupancy"])):
             raise SystemExit(f"bench: GPU results differ from the oracle on the CPU sample (rel {rel.max():.3g})")
         build = "gcc -O2 -march=native -ffp-contract=off, built on this box" if native else "gcc -O2 -ffp-contract=off (portable build)"
+        protocol = f"{n_warm} warm-up pass{'es' if n_warm > 1 else ''}, median of {len(all_rates)} passes"
         cpu = {"value": all_rate, "unit": "Msamples/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_all} epochs ({n_all * spe * 8 / 2**20:.0f} MiB) of the GPU batch x {all_reps} per pass, "
+               "sample": f"first {n_all} epochs ({n_all * spe * 8 / 2**20:.0f} MiB) of " + ("rank 0's" if world > 1 else "the") + f" GPU batch x {all_reps} per pass, "
                          f"oracle/crn_oracle.c (liquid-dsp-style fp32 radix-2 restated; {build}) on {cores} threads, "
-                         f"median of {len(all_rates)} passes; {cores} threads = what this process may run at once "
-                         f"(host: {hw} hardware threads; {why}); thread_sweep_Msamples_s is for information",
-               "thread_sweep_Msamples_s": {str(k): round(v, 1) for k, v in sweep.items()},
+                         f"{protocol} (BASELINE.md §3); {cores} threads = what this process may run at once "
+                         f"(host: {hw} hardware threads; {why}); thread_sweep_Msamples_s is for information"
+                         + (f"; measured on rank 0 after the timed region, the other {world - 1} ranks idle" if world > 1 else ""),
+               "thread_sweep_Msamples_s": {str(k): round(v, 1) for k, v in sorted(sweep.items())},
                "passes": all_rates,
                "one_thread": {"value": one_rate, "unit": "Msamples/s", "cores": 1,
-                              "sample": f"first {n_one} epochs x {one_reps} per pass, median of {len(one_rates)} passes: the "
+                              "sample": f"first {n_one} epochs x {one_reps} per pass, {protocol}: the "
                                         "reference's own topology (one CE pthread, src/extensible_cognitive_radio.cpp:1761-1808)",
                               "passes": one_rates}}
+    if world > 1:
+        dist.barrier()   # (gloo's --stage-timeout covers a rank 0 that never arrives)
 
     # ---- N > 1: what every rank measured and what RCCL itself says the communicator is ------------------
     rccl, per_rank = None, None
@@ -656,12 +719,18 @@ def main():
         comms = [r["comm"] for r in everyone]
         rccl = {"nranks": comms[0]["nranks"], "nranks_seen_by_every_rank": sorted({c["nranks"] for c in comms}),
                 "user_ranks": [c["rank"] for c in comms], "rank0_device": comms[0]["rccl_device"],
-                "devices": [c["rccl_device"] for c in comms], "version": comms[0]["rccl_version"], "library": comms[0]["library"],
+                "devices": [c["rccl_device"] for c in comms], "pci_bus_ids": [c["pci_bus_id"] for c in comms],
+                "version": comms[0]["rccl_version"], "library": comms[0]["library"],
                 "gathers_per_rank": sorted({c["gathers"] for c in comms}), "bytes_per_rank_per_gather": comms[0]["bytes_per_rank"],
                 "source": "crn_comm_info on every rank: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion of the "
-                          "communicator the gathers ran on (version 0 = a stand-in library behind $CRN_RCCL_LIB)"}
+                          "communicator the gathers ran on (version 0 = a stand-in library behind $CRN_RCCL_LIB); pci_bus_ids = "
+                          "hipDeviceGetPCIBusId of the device RCCL bound each rank to"}
         if rccl["nranks_seen_by_every_rank"] != [world] or rccl["user_ranks"] != list(range(world)):
             raise SystemExit(f"bench: the communicator is not the {world} ranks of this job: {rccl}")
+        # N ranks on N different GPUs: real RCCL refuses two ranks per device, and the line must show it did not have to — every rank names
+        # another physical device (a stand-in library, version 0, shares one GPU between the ranks by design: tests only)
+        if rccl["version"] != 0 and len(set(rccl["pci_bus_ids"])) != world:
+            raise SystemExit(f"bench: {world} ranks but {len(set(rccl['pci_bus_ids']))} distinct GPUs: {rccl['pci_bus_ids']}")
         slow = max(everyone, key=lambda r: r["kernel_ms_mean"])
         fast = min(everyone, key=lambda r: r["kernel_ms_mean"])
         per_rank = {"kernel_ms_mean": [r["kernel_ms_mean"] for r in everyone], "kernel_ms_mean_min": fast["kernel_ms_mean"],
@@ -696,12 +765,15 @@ def main():
             line["roofline_valu"] = roofline_valu
             line["roofline"]["note"] = "this mode is VALU-issue-bound, not HBM-bound: see roofline_valu"
         print(json.dumps(line), file=json_out, flush=True)
+    stage("shutdown")
     if ex is not None:
         torch.cuda.synchronize()
         ex.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if dog is not None:
+        dog.stop()
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CRN_ABI_VERSION 3
+#define CRN_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define CRN_API __attribute__((visibility("default")))
@@ -341,8 +341,9 @@ CRN_API int crn_comm_create(int32_t device, int32_t rank, int32_t world, const u
                             int64_t bytes_per_rank, int32_t depth, crn_comm **out);
 /* What the communicator is, asked of RCCL itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion on the
  * communicator crn_comm_create built — not an echo of its arguments), so that a caller can state, and a reader of its output can
- * check, that the collective really spans `nranks` ranks: bench.py puts every rank's answer into its N > 1 JSON line.  Fields RCCL
- * cannot answer (a library without the query) read -1.  Not collective; never blocks. */
+ * check, that the collective really spans `nranks` ranks on `nranks` different GPUs: bench.py puts every rank's answer into its N > 1
+ * JSON line and refuses to report a real-RCCL run whose ranks do not name N distinct PCI devices.  Fields RCCL cannot answer (a library
+ * without the query) read -1.  Not collective; never blocks. */
 typedef struct crn_comm_info_t {
   int32_t nranks;         /* ncclCommCount */
   int32_t rank;           /* ncclCommUserRank */
@@ -353,6 +354,8 @@ typedef struct crn_comm_info_t {
   int64_t bytes_per_rank;
   int64_t gathers;        /* all-gathers queued through crn_comm_allgather so far */
   char library[128];      /* the name the RCCL library was loaded under (librccl.so.1, or $CRN_RCCL_LIB) */
+  char pci_bus_id[32];    /* hipDeviceGetPCIBusId of rccl_device (of `device` when RCCL cannot say): "0000:05:00.0" — the physical GPU, whatever
+                             ordinal a launcher's device isolation gave it in this process (ABI version 4) */
 } crn_comm_info_t;
 CRN_API int crn_comm_info(crn_comm *c, crn_comm_info_t *out);
 /* Device address of the block step `step` writes (slot step % depth).  If that slot's previous gather

@@ -18,7 +18,7 @@ SC16_LIB_PATH = os.path.join(HERE, "libcrnsense_sc16.so")
 PLAIN_LIB_PATH = os.path.join(HERE, "libcrnsense_plain.so")
 LIQUID_SHIM_PATH = os.path.join(HERE, "libcrnliquidfft.so")  # include/crn_liquid_fft.h
 
-CRN_ABI_VERSION = 3
+CRN_ABI_VERSION = 4
 CRN_ERR_ARG = -1
 CRN_ERR_BUSY = -5
 CRN_MAX_BANDS = 80
@@ -102,7 +102,7 @@ class IngestStats(C.Structure):
 class CommInfo(C.Structure):
     _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("rccl_device", C.c_int32), ("rccl_version", C.c_int32),
                 ("device", C.c_int32), ("depth", C.c_int32), ("bytes_per_rank", C.c_int64), ("gathers", C.c_int64),
-                ("library", C.c_char * 128)]
+                ("library", C.c_char * 128), ("pci_bus_id", C.c_char * 32)]
 
 
 class SynthCfg(C.Structure):
@@ -550,7 +550,7 @@ class Comm:
         check(lib().crn_comm_info(self._c, C.byref(ci)), "crn_comm_info")
         return {"nranks": ci.nranks, "rank": ci.rank, "rccl_device": ci.rccl_device, "rccl_version": ci.rccl_version,
                 "device": ci.device, "depth": ci.depth, "bytes_per_rank": ci.bytes_per_rank, "gathers": ci.gathers,
-                "library": ci.library.decode(errors="replace")}
+                "library": ci.library.decode(errors="replace"), "pci_bus_id": ci.pci_bus_id.decode(errors="replace")}
 
     def close(self):
         if self._c:

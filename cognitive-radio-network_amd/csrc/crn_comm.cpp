@@ -181,6 +181,9 @@ int crn_comm_info(crn_comm *c, crn_comm_info_t *out) {
   if (r.CommCuDevice) { int v = -1; NCCL_TRY(r.CommCuDevice(c->comm, &v)); out->rccl_device = v; }
   if (r.GetVersion) { int v = -1; NCCL_TRY(r.GetVersion(&v)); out->rccl_version = v; }
   std::snprintf(out->library, sizeof(out->library), "%s", r.path.c_str());
+  // the physical device behind the ordinal (ranks isolated by HIP_VISIBLE_DEVICES all call theirs 0)
+  if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), out->rccl_device >= 0 ? out->rccl_device : c->device) != hipSuccess)
+    out->pci_bus_id[0] = 0;
   return CRN_OK;
 }
 

@@ -97,6 +97,10 @@ struct crn_ingest {
   std::condition_variable cv_work, cv_free;
   std::deque<int> work;                    // batches to launch, in order
   std::deque<crn_epoch_result> ready;
+  // crn_ingest_poll runs in every execute() — tens of thousands of times a second when the CE thread spins (ce_timeout_ms = 0) — and a
+  // result arrives once per sensing period: the poll reads this flag first and takes `mu` only when there is something to fetch, so
+  // that execute() (CE_mutex held) never queues behind a launcher thread the scheduler has put to sleep with `mu` in hand.
+  std::atomic<bool> poll_hint{false};      // ready is not empty, or err_code is set (written under mu)
   int err_code = CRN_OK;                   // first failure on the launcher thread, reported by the next call
   std::string err_msg;
   bool stop = false;
@@ -268,6 +272,7 @@ void launcher_main(crn_ingest *g) {
         if (g->err_code == CRN_OK) {
           g->err_code = CRN_ERR_DEVICE;
           g->err_msg = "ingest launch failed, batch dropped: " + err;
+          g->poll_hint.store(true, std::memory_order_release);
         }
         g->n_failed++;
         release_batch(g, g->batch[i]);
@@ -316,6 +321,7 @@ void launcher_main(crn_ingest *g) {
         g->err_code = CRN_ERR_DEVICE;
         g->err_msg = cal_err;
       }
+      if (!g->ready.empty() || g->err_code != CRN_OK) g->poll_hint.store(true, std::memory_order_release);
       g->lat_us_sum += us;
       if (us > g->lat_us_max) g->lat_us_max = us;
       if (g->trace) {
@@ -336,6 +342,7 @@ void launcher_main(crn_ingest *g) {
       if (g->err_code == CRN_OK) {
         g->err_code = CRN_ERR_DEVICE;
         g->err_msg = std::string("ingest batch failed on the device: ") + hipGetErrorString(q);
+        g->poll_hint.store(true, std::memory_order_release);
       }
       g->n_failed++;
       release_batch(g, b);
@@ -359,6 +366,7 @@ int sticky_error(crn_ingest *g) {
   if (g->err_code == CRN_OK) return CRN_OK;
   const int code = g->err_code;
   g->err_code = CRN_OK;
+  g->poll_hint.store(!g->ready.empty(), std::memory_order_release);
   return crn::fail(code, g->err_msg);
 }
 
@@ -618,17 +626,20 @@ int crn_ingest_poll(crn_ingest *g, crn_epoch_result *out, int32_t max_results, i
     }
   }
   int n = 0;
+  if (!g->poll_hint.load(std::memory_order_acquire)) return CRN_OK;   // nothing has come back since the last poll: no lock
   {
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->err_code != CRN_OK) {
       const int code = g->err_code;
       g->err_code = CRN_OK;
+      g->poll_hint.store(!g->ready.empty(), std::memory_order_release);
       return crn::fail(code, g->err_msg);
     }
     while (n < max_results && !g->ready.empty()) {
       out[n++] = g->ready.front();
       g->ready.pop_front();
     }
+    g->poll_hint.store(!g->ready.empty(), std::memory_order_release);
   }
   g->polled += n;
   *n_out = n;

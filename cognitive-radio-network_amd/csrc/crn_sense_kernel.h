@@ -387,11 +387,23 @@ static hipError_t launch_dealt_win(const SenseParams &p, hipStream_t stream) {
   return launch_dealt_cfg<Cfg<R3, 1, true, false, false, true, false, 1, false, true, kO | kHannSym>>(p, stream);
 }
 
+// The register form of the epoch close applies to band plans the host could cut into row entries
+// (crn_api.cpp) when no per-bin spectrum is stored.
+static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
+// ... and pass 3 / the accumulate keep only the reference channel plan's registers when every band bin sits in one of them.
+template <int R3>
+static bool ref_plan_rows(const SenseParams &p) { return reg_bands(p) && ref_acc_mask(R3) != 0xFFFFu && (p.acc_mask & ~ref_acc_mask(R3)) == 0; }
+// Which close a launch gets is ONE rule for the streaming and the dealt-frame kernels (their outputs are bit-identical because they sum
+// in the same order): the register close for |X| mode, and for energy mode on whole frames or on the reference plan; the LDS walk
+// otherwise (energy mode, short packets, another small plan; every plan too big for row entries; every spectrum request).
+template <int R3>
+static bool register_close(const SenseParams &p, bool mag) { return reg_bands(p) && (mag || p.L == Geo<R3>::N || ref_plan_rows<R3>(p)); }
+
 // Dealt-frame forms of a size: |X| or energy, band sums from registers or through the LDS walk; short frames are masked at run time.
 template <int R3, int OPT>
 static hipError_t launch_dealt(const SenseParams &p, bool mag, hipStream_t stream) {
   constexpr int kO = kSpread | kLdsBlk | kDeal | OPT;
-  const bool regb = p.n_row_entries > 0 && p.spectrum == nullptr;
+  const bool regb = register_close<R3>(p, mag);
   if (mag) {
     if (regb) return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, false, true, kO | kRegBands>>(p, stream);
     return launch_dealt_cfg<Cfg<R3, 1, true, false, true, false, false, 1, false, true, kO>>(p, stream);
@@ -436,10 +448,6 @@ static hipError_t launch_cfg(const SenseParams &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// The register form of the epoch close applies to band plans the host could cut into row entries
-// (crn_api.cpp) when no per-bin spectrum is stored.
-static bool reg_bands(const SenseParams &p) { return p.n_row_entries > 0 && p.spectrum == nullptr; }
-
 // The forms every size has, by mode / window / packet length / close.  What is specialised is what BASELINE.json's configurations and
 // the engine run: whole frames (FULL: no zero-padding mask) where the band plan is the reference's (kRows | kRegBands) or a small one in
 // energy mode (kRegBands); everything else — table windows, |X| mode with another plan or a spectrum request, short packets with a
@@ -451,11 +459,11 @@ template <int R3, int NBUF, bool PREFETCH, bool NT, bool TW2LDS, int OCC, bool P
           int WHICH = 0, bool PRUNE = true, bool ENERGY_FULL = true>
 static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipStream_t stream) {
   const bool full = p.L == Geo<R3>::N;
-  const bool regb = reg_bands(p);  // small band plan, no spectrum: band sums from registers
+  const bool regb = register_close<R3>(p, mag);  // small band plan, no spectrum: band sums from registers (see register_close)
   // ... and when every band bin sits in a register the reference channel plan also uses (ref_acc_mask), pass 3 and the accumulate
   // keep only those registers: 7 of 16 at N = 512 (where the reference's |X| costs a square root per bin and frame), 12 / 11 / 7 at
   // 1024 / 2048 / 4096
-  [[maybe_unused]] const bool prune = PRUNE && regb && ref_acc_mask(R3) != 0xFFFFu && (p.acc_mask & ~ref_acc_mask(R3)) == 0;
+  [[maybe_unused]] const bool prune = PRUNE && ref_plan_rows<R3>(p);
 #define CRN_GO(MAGV, WINV, FULLV, EXTRA) return launch_cfg<Cfg<R3, NBUF, PREFETCH, NT, MAGV, WINV, TW2LDS, OCC, FULLV, PK, OPT | (EXTRA)>>(p, stream)
   if constexpr (WHICH != 1) {   // table windows: one form per mode
     if (win) { if (mag) CRN_GO(true, true, false, 0); else CRN_GO(false, true, false, 0); }
@@ -471,6 +479,9 @@ static hipError_t launch_default(const SenseParams &p, bool mag, bool win, hipSt
     if (regb) {                 // another small plan: register close for |X| (any packet length) and for energy on whole frames
       if (mag) CRN_GO(true, false, false, kRegBands);
       if constexpr (ENERGY_FULL) { if (full) CRN_GO(false, false, true, kRegBands); }
+      // (a unit without the reference-plan forms — the wire-format one — closes that plan's short packets from registers all the same:
+      // the same sums in the same order as the float path's pruned form)
+      if constexpr (!PRUNE) { if (!full) CRN_GO(false, false, false, kRegBands); }
     }
     if (mag) CRN_GO(true, false, false, 0);   // any plan, spectrum requests: the LDS walk
     if constexpr (ENERGY_FULL) { if (full) CRN_GO(false, false, true, 0); }

@@ -16,6 +16,7 @@
 // ---- host stand-ins for the HIP runtime calls crn_comm.cpp makes ("device" memory is host memory, streams are synchronous) ----
 extern "C" {
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int dev) { snprintf(buf, (size_t)len, "0000:%02x:00.0", 5 + dev); return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
@@ -67,6 +68,7 @@ static void rank_main(int rank, int world, const uint8_t *id, int64_t bytes, int
   REQUIRE(crn_comm_info(c, &info) == CRN_OK);
   REQUIRE(info.nranks == world && info.rank == rank && info.depth == depth && info.bytes_per_rank == bytes);
   REQUIRE(info.gathers == 3 * depth + 2 && info.rccl_version == 0 && strstr(info.library, "fake_rccl") != NULL);
+  REQUIRE(strncmp(info.pci_bus_id, "0000:", 5) == 0 && strlen(info.pci_bus_id) == 12);   // the device behind RCCL's (here: crn_comm_create's) ordinal
   REQUIRE(crn_comm_info(c, NULL) == CRN_ERR_ARG && crn_comm_info(NULL, &info) == CRN_ERR_ARG);
   uint8_t *p = NULL;
   REQUIRE(crn_comm_local(c, -1, NULL, &p) == CRN_ERR_ARG);

@@ -11,7 +11,10 @@
 // iq.bin holds 4 segments (idle, CH1, CH2, CH3 driven) of <packets_per_segment> packets; the "radio" replays the
 // current segment's packets in a loop at the real packet rate (L / 13 Msps) and moves to the next segment every
 // 0.25 s.  Printed: one line per decision with the segment(s) its 10 frames came from, then what the rx thread
-// paid for the hand-off (time spent waiting for CE_mutex per packet) and how many packets got through.
+// paid for the hand-off (time spent waiting for CE_mutex per packet) and how many packets got through; the
+// distribution of execute()'s duration with its ten longest calls attributed (which event, which packet of the
+// epoch, whether a decision came back in it), and beside it a CONTROL: two clock reads with nothing between them,
+// taken in the same loop — what the operating system alone does to this thread.
 #include <errno.h>
 #include <math.h>
 #include <pthread.h>
@@ -121,7 +124,10 @@ int main(int argc, char **argv) {
   pthread_create(&rx, NULL, rx_worker, &s);
 
   // CE worker (this thread), :1775-1803
-  std::vector<float> exec_us;
+  std::vector<float> exec_us, null_us;
+  struct Call { float us; double t; char rx; short k; char closed; };   // k: packets of the open epoch the engine held before the call
+  std::vector<Call> calls;
+  const double t_start = now_s();
   std::deque<int> open_epoch;                 // segments of the frames the engine has taken for the epoch being staged
   std::deque<std::vector<int> > awaiting;     // epochs handed to the GPU, decision not yet reported
   long seen = 0, taken = 0;
@@ -138,9 +144,14 @@ int main(int argc, char **argv) {
       s.ecr.CE_metrics.CE_event = ExtensibleCognitiveRadio::TIMEOUT;
     const bool rx_event = s.ecr.CE_metrics.CE_event == ExtensibleCognitiveRadio::USRP_RX_SAMPS;
     const int seg = s.seg_of_buffer;
+    const long closed_before = engine->epochs_closed;
     const double a = now_s();
     engine->execute();                                   // :1802, CE_mutex held
-    exec_us.push_back((float)((now_s() - a) * 1e6));
+    const double b = now_s();
+    const double c = now_s();                            // control: nothing between b and c
+    exec_us.push_back((float)((b - a) * 1e6));
+    null_us.push_back((float)((c - b) * 1e6));
+    calls.push_back(Call{(float)((b - a) * 1e6), a - t_start, (char)rx_event, (short)open_epoch.size(), (char)(engine->epochs_closed != closed_before)});
     if (rx_event && !engine->packets_dropped) {
       taken++;
       open_epoch.push_back(seg);
@@ -171,6 +182,12 @@ int main(int argc, char **argv) {
          engine->epochs_closed);
   if (n) printf("rx_wait_for_CE_mutex_us n %zu median %.3f p99 %.3f max %.3f\n", n, s.rx_wait_us[n / 2], s.rx_wait_us[(size_t)(n * 0.99)], s.rx_wait_us[n - 1]);
   if (m) printf("execute_us n %zu median %.3f p99 %.3f p9999 %.3f max %.3f\n", m, exec_us[m / 2], exec_us[(size_t)(m * 0.99)], exec_us[(size_t)(m * 0.9999)], exec_us[m - 1]);
+  std::sort(null_us.begin(), null_us.end());
+  if (m) printf("control_two_clock_reads_us n %zu median %.3f p99 %.3f p9999 %.3f max %.3f\n", m, null_us[m / 2], null_us[(size_t)(m * 0.99)], null_us[(size_t)(m * 0.9999)], null_us[m - 1]);
+  std::sort(calls.begin(), calls.end(), [](const Call &x, const Call &y) { return x.us > y.us; });
+  for (size_t i = 0; i < calls.size() && i < 10; i++)
+    printf("longest_execute %zu: %.3f us at t %.4f s, event %s, packet %d of the epoch, %s\n", i + 1, calls[i].us, calls[i].t,
+           calls[i].rx ? "USRP_RX_SAMPS" : "TIMEOUT", calls[i].rx ? calls[i].k + 1 : 0, calls[i].closed ? "a decision was reported in it" : "no decision");
   engine->release();
   return 0;
 }

@@ -142,18 +142,29 @@ def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
         from test_comm import _run_group   # own process group: a timeout must not leave the two ranks behind
         out = _run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                          "--epochs", "2048", "--cpu-epochs", "0", *extra], 300, env, cwd=ROOT)
+                          "--epochs", "2048", "--cpu-epochs", "32", *extra], 300, env, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
         assert len(lines) == 1, out.stdout[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["epochs_per_gpu"] == 2048
         assert d["config"]["parallelism"].startswith("stream-sharded x2") and "crn_comm_" in d["config"]["parallelism"]
-        assert d["cpu_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0
+        assert d["value"] > 0 and d["ms_per_step"] > 0
+        _check_cpu_baseline_of_an_n_gt_1_line(d, 2)
         assert d["config"]["rccl"]["nranks"] == 2 and d["config"]["rccl"]["user_ranks"] == [0, 1]
+        assert len(d["config"]["rccl"]["pci_bus_ids"]) == 2
 
 
-def _self_launched(n, *extra, epochs="512", timeout=600):
+def _check_cpu_baseline_of_an_n_gt_1_line(d, n):
+    """north_star: throughput at 1 / 2 / 4 / 8 GPUs NEXT TO the CPU path timed on the same box's host cores (count stated)."""
+    c = d["cpu_baseline"]
+    assert c is not None and c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "Msamples/s"
+    assert c["one_thread"]["value"] > 0 and c["one_thread"]["cores"] == 1
+    assert "rank 0" in c["sample"] and f"the other {n - 1} ranks idle" in c["sample"] and "threads" in c["sample"]
+    assert "not re-measured at N > 1" in (d["roofline"]["traffic_source"] or "not re-measured at N > 1")
+
+
+def _self_launched(n, *extra, epochs="512", timeout=600, cpu_epochs="0"):
     """`python bench.py --gpus n` with NO launcher and no WORLD_SIZE in the environment — the shape of the driver's single-GPU command
     at n > 1 — on the one GPU of the box, the ranks over tests/harness/libfake_rccl_mp.so."""
     fake = os.path.join(ROOT, "tests", "harness", "libfake_rccl_mp.so")
@@ -162,7 +173,7 @@ def _self_launched(n, *extra, epochs="512", timeout=600):
     env.update(CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
     from test_comm import _run_group
     out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
-                      "--epochs", epochs, "--cpu-epochs", "0", *extra], timeout, env, cwd=ROOT)
+                      "--epochs", epochs, "--cpu-epochs", cpu_epochs, *extra], timeout, env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-2000:]          # the parent relays exactly rank 0's line
@@ -185,14 +196,18 @@ def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode, 
     the parent, exit non-zero) and rank 0's single JSON line is relayed."""
     # weak: 1024 epochs on every rank.  strong: 8192 epochs in all, split eight ways — a share far below 4 GiB, so every rank
     # alternates its launches between two streams (four exchange slots)
-    d = _self_launched(8, *mode, "--scaling", scaling, epochs="1024" if scaling == "weak" else "8192")
+    d = _self_launched(8, *mode, "--scaling", scaling, epochs="1024" if scaling == "weak" else "8192", cpu_epochs="32")
     assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["epochs_per_gpu"] == 1024
     assert d["config"]["epochs_per_step_all_gpus"] == 8192 and d["config"]["streams_per_gpu"] == (2 if scaling == "strong" else 1)
     assert d["config"]["parallelism"].startswith("stream-sharded x8") and "crn_comm_" in d["config"]["parallelism"]
-    assert d["cpu_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
-    # the line proves what the collective saw: eight ranks, every one of them counted eight, in rank order, each with its gathers
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
+    _check_cpu_baseline_of_an_n_gt_1_line(d, 8)       # every N > 1 line carries the CPU figure (rank 0 measures it after the timed region)
+    # the line proves what the collective saw: eight ranks, every one of them counted eight, in rank order, each with its gathers,
+    # and which physical GPU each was bound to (here one GPU eight times: the stand-in, version 0, is the only library allowed that)
     r = d["config"]["rccl"]
     assert r["nranks"] == 8 and r["nranks_seen_by_every_rank"] == [8] and r["user_ranks"] == list(range(8)) and len(r["devices"]) == 8
+    assert len(r["pci_bus_ids"]) == 8 and all(isinstance(b, str) and len(b) >= 7 and b.count(":") == 2 for b in r["pci_bus_ids"])
+    assert len(set(r["pci_bus_ids"])) == 1
     assert "fake_rccl_mp" in r["library"] and r["version"] == 0          # (the stand-in says so)
     pr = d["roofline"]["per_rank"]
     assert len(pr["kernel_ms_mean"]) == 8 and pr["kernel_ms_mean_min"] <= pr["kernel_ms_mean_max"] and 0 <= pr["slowest_rank"] < 8
@@ -210,3 +225,42 @@ def test_bench_self_launch_propagates_a_rank_failure(built):
     out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--epochs", "64",
                       "--cpu-epochs", "0", "--fft", "3000"], 300, env, cwd=ROOT)
     assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_bench_a_hung_rank_ends_the_job_within_the_stage_timeout(built):
+    """Fail-fast at N > 1 (VERDICT r04 next #1b): a rank that HANGS — stopped with SIGSTOP as soon as it exists, so it never joins the
+    others — must cost --stage-timeout (300 s by default, 20 s here), not gloo's default 30 minutes: the live rank gives up in
+    gloo or at its watchdog, exits non-zero, the launcher kills the stopped one, the parent relays the failure and prints no line."""
+    import signal
+    import time
+    import psutil
+    fake = os.path.join(ROOT, "tests", "harness", "libfake_rccl_mp.so")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
+    t0 = time.monotonic()
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs", "256",
+                          "--cpu-epochs", "0", "--stage-timeout", "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                         cwd=ROOT, start_new_session=True)
+    stopped = None
+    try:
+        while stopped is None and time.monotonic() - t0 < 120 and p.poll() is None:
+            for ch in psutil.Process(p.pid).children(recursive=True):
+                try:
+                    if ch.environ().get("RANK") == "1" and "bench.py" in " ".join(ch.cmdline()):
+                        ch.send_signal(signal.SIGSTOP)
+                        stopped = ch.pid
+                        break
+                except (psutil.NoSuchProcess, psutil.AccessDenied):
+                    pass
+            time.sleep(0.005)
+        assert stopped is not None, "rank 1 never appeared"
+        out, err = p.communicate(timeout=150)
+    finally:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+    took = time.monotonic() - t0
+    assert p.returncode != 0 and not [ln for ln in out.splitlines() if ln.strip().startswith("{")], (p.returncode, out[-500:])
+    assert took < 120, took      # stage timeout 20 s + the launcher's own 30 s grace before it kills the stopped rank
+    assert not psutil.pid_exists(stopped) or psutil.Process(stopped).status() == psutil.STATUS_ZOMBIE

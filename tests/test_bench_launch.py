@@ -93,3 +93,18 @@ def test_two_self_launched_ranks_reach_the_gpu_check_without_a_gpu():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout
     assert "needs a GPU" in r.stderr
+
+
+def test_watchdog_ends_a_rank_stuck_in_a_stage():
+    """bench.py's per-stage watchdog (N > 1): a rank whose stage outlives --stage-timeout says where it was and exits 6 — from a thread,
+    because the main thread is blocked (here: asleep; in a real run inside ncclCommInitRank or a device synchronise)."""
+    code = ("import importlib.util, time\n"
+            f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r})\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "d = b.Watchdog(0.5, 3)\n"
+            "d.pet('first'); time.sleep(0.2); d.pet('the stage that hangs'); time.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 6 and "rank 3" in r.stderr and "the stage that hangs" in r.stderr
+    code = code.replace("time.sleep(30)", "d.stop(); time.sleep(1.5)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
