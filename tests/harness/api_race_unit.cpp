@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,7 +43,11 @@ hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipS
   return hipSuccess;
 }
 int sense_num_variants() { return 27; }
-hipError_t launch_nop(hipStream_t) { return hipSuccess; }
+std::atomic<long long> g_warm{0};
+}
+std::atomic<long> g_pauses{0};
+namespace crn {
+hipError_t launch_nop(hipStream_t) { g_warm++; return hipSuccess; }   // crn_sense_warm_stream: the launcher thread's empty launch at a pre-wake
 int sense_deal_rounds(int, bool, bool, bool, int, size_t) { return 0; }
 unsigned sense_ref_acc_mask(int) { return 0xFFFFu; }
 bool sense_variant_available(int v) { return v == 0; }
@@ -81,14 +86,31 @@ int main() {
   REQUIRE(crn_ingest_create(h, 2, 256, 2, &g) == CRN_OK);
   REQUIRE(crn_sense_destroy(h) == CRN_ERR_STATE);      // a ring is attached: the handle stays (its launcher thread launches through it)
 
-  std::atomic<bool> stop{false};
+  std::atomic<bool> stop{false}, slow{false};
   std::thread pusher([&] {
     std::vector<float> pkt(256 * 2, 0.5f);
     crn_epoch_result r[8];
     int32_t n = 0;
+    long pushed = 0;
+    int64_t paused_at = -1;
     while (!stop.load()) {
+      // second phase: a pause after every batch, so that the ring's stream sits idle for more than 2 ms and the next batch's pre-wake makes
+      // the launcher thread call crn_sense_warm_stream (which reads the handle's device without the lock) while the plan is being swapped
+      // (the pause follows a hand-off — the ring's batch counter moved — so it falls between two batches whatever phase the two streams are in)
+      if (slow.load()) {
+        crn_ingest_stats st;
+        if (crn_ingest_get_stats(g, &st) == CRN_OK && st.batches != paused_at) {
+          paused_at = st.batches;
+          g_pauses++;
+          std::this_thread::sleep_for(std::chrono::milliseconds(8));
+        }
+      }
       for (int s = 0; s < 2; s++) {
         const int rc = crn_ingest_push(g, s, pkt.data());
+        pushed += rc == CRN_OK;
+        // ... and packets come at a radio's pace in that phase (the pre-wake is ten packet times ahead of the hand-off: pushed back to
+        // back, the hand-off overtakes the launcher thread's wake-up and clears the hint before it is seen)
+        if (slow.load()) std::this_thread::sleep_for(std::chrono::microseconds(40));
         if (rc == CRN_ERR_BUSY) (void)crn_ingest_wait(g);
         else if (rc != CRN_OK) { std::fprintf(stderr, "push: %s\n", crn_last_error()); std::exit(1); }
       }
@@ -111,6 +133,22 @@ int main() {
     if (it > 200000) break;
     std::this_thread::yield();
   }
+  slow.store(true);
+  const long long warm_before = crn::g_warm.load();
+  const auto t_slow = std::chrono::steady_clock::now();
+  for (int it = 0; crn::g_warm.load() < warm_before + 8 && std::chrono::steady_clock::now() - t_slow < std::chrono::seconds(20); it++) {
+    REQUIRE(crn_sense_set_bands(h, (it & 1) ? plan_b : plan_a, 4, 4, nullptr) == CRN_OK);
+    REQUIRE(crn_sense_synchronize(h, nullptr) == CRN_OK);    // (reads the device field too)
+    std::this_thread::sleep_for(std::chrono::microseconds(200));   // (std::mutex is not fair: leave the launcher thread a turn at the handle)
+  }
+  if (crn::g_warm.load() < warm_before + 8) {
+    crn_ingest_stats st;
+    (void)crn_ingest_get_stats(g, &st);
+    std::fprintf(stderr, "DEBUG warm %lld -> %lld; batches %lld packets %lld dropped %lld epochs_ready %lld pauses %ld\n", warm_before, crn::g_warm.load(),
+                 (long long)st.batches, (long long)st.packets, (long long)st.dropped, (long long)st.epochs_ready, g_pauses.load());
+  }
+  REQUIRE(crn::g_warm.load() >= warm_before + 8);            // the pre-wake's warm-up launches did run against the swaps
+  slow.store(false);
   // a change of the number of bands is refused while the ring is attached (its result buffers were sized for 4)
   const crn_band_seg three[3] = {{600, 620, 0}, {8, 24, 1}, {110, 170, 2}};
   const float thr3[3] = {1, 2, 3};

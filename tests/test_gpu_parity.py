@@ -353,8 +353,10 @@ def test_shipped_library_carries_no_measurement_variants(built):
 def test_plan_pruned_kernels_equal_the_full_ones(built, n, mode):
     """With the reference channel plan (at any size) and no spectrum output the launch runs kernels whose pass 3 and accumulate keep
     only the registers that plan reaches (7 / 12 / 11 / 7 of 16 at N = 512 / 1024 / 2048 / 4096); variant 2 runs the full kernels.
-    Same operations on the kept bins: features, network outputs, decisions and occupancy are bit-identical — whole frames and the
-    radio's 364-sample packets; and a band table that reaches other registers silently gets the full kernel (checked against the
+    Same operations on the kept bins: features, network outputs, decisions and occupancy are bit-identical — whole frames and, in |X|
+    mode, the radio's 364-sample packets.  (Energy mode on short packets: the reference-plan form closes from registers, what any
+    other plan runs closes through the LDS walk — csrc/crn_sense_kernel.h, register_close — so the band sums come in another order
+    and agree to rounding, 2e-6.)  A band table that reaches other registers silently gets the full kernel (checked against the
     oracle)."""
     cfg = cs.cfg_energy_scaled(n, 4.0) if mode == "energy" else cs.cfg_reference_scaled(n)
     n_epochs = 37
@@ -368,8 +370,12 @@ def test_plan_pruned_kernels_equal_the_full_ones(built, n, mode):
             assert ("PASS3_ROWS" in name) == (v == 0), name
             res.append(s.run_host(iq, n_epochs, L=L))
             s.close()
+        same_close = mode == "mag" or L == n
         for k in ("features", "ann_out", "decision", "occupancy"):
-            assert np.array_equal(res[0][k], res[1][k]), (k, L)
+            if same_close or k != "features":
+                assert np.array_equal(res[0][k], res[1][k]), (k, L)
+            else:
+                assert np.allclose(res[0][k], res[1][k], rtol=2e-6, atol=0), (k, L)
         want = orc.run(cfg, iq, n_epochs, L=L)
         assert (np.abs(res[0]["features"] - want["features"]) / np.abs(want["features"])).max() < FEATURE_TOL
         assert np.array_equal(res[0]["decision"], want["decision"])

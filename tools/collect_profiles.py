@@ -3,7 +3,7 @@
 profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(R, "gpurun_out", tag)
 DST = os.path.join(R, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -30,7 +30,10 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("welch_spans.txt", f"{tag}_welch_spans.txt"), ("soak.txt", f"{tag}_soak_round.txt"),
                  ("dealt_frames_ab.txt", f"{tag}_dealt_frames_ab.txt"), ("engine_idle_gap.txt", f"{tag}_engine_idle_gap.txt"),
                  ("per_bin_error_vs_snr.txt", f"{tag}_per_bin_error_vs_snr.txt"),
-                 ("engine_between_ecr_threads.txt", f"{tag}_engine_between_ecr_threads.txt")):
+                 ("engine_between_ecr_threads.txt", f"{tag}_engine_between_ecr_threads.txt"),
+                 ("asm_filter_byte_equal.txt", f"{tag}_asm_filter_byte_equal.txt"),
+                 ("bench_wire_format_optional_library.json", f"{tag}_bench_wire_format_optional_library.json"),
+                 ("bench_2ranks_one_gpu.json", f"{tag}_bench_two_ranks_one_gpu_stand_in_wire.json")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
         shutil.copy(m[-1], os.path.join(DST, dst))

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round evidence (tag $TAG, default r04), one gpurun call, one box: GPU tests, smoke, every bench line (single GPU; N = 8 rehearsed in
+# Round evidence (tag $TAG, default r05), one gpurun call, one box: GPU tests, smoke, every bench line (single GPU; N = 8 rehearsed in
 # both scaling modes over the stand-in RCCL), rocprofv3 kernel stats of the headline command, HBM traffic counters (separate --pmc
 # passes per workload), SQ / GRBM counter groups, the engine's execute() latency, host-buffer (PCIe-inclusive) rate, probes.
-#   gpurun --timeout 3600 -- 'bash tools/gpu_round.sh'   then   python tools/collect_profiles.py r04
+#   gpurun --timeout 3600 -- 'bash tools/gpu_round.sh'   then   python tools/collect_profiles.py r05
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -21,6 +21,8 @@ timeout 300 python bench.py --mode scan --cpu-epochs 0 --force-collective > $O/b
 timeout 300 python bench.py --variant 2 --cpu-epochs 0 --no-alt > $O/bench_unpruned.json 2> $O/bench_unpruned.err
 timeout 300 python bench.py --fft 512 --cpu-epochs 0 > $O/bench_e512.json 2> $O/bench_e512.err
 timeout 300 python bench.py --fft 2048 --cpu-epochs 0 > $O/bench_e2048.json 2> $O/bench_e2048.err
+# the optional wire-format library (make SC16=1): one line, so that what is no longer in the shipped library is still seen to work
+[ -f cognitive-radio-network_amd/libcrnsense_sc16.so ] && timeout 300 python bench.py --wire-format --cpu-epochs 0 > $O/bench_wire_format_optional_library.json 2> $O/bench_wire_format.err
 # the driver's command shape; the N = 1 end of the strong-scaling curve and its per-GPU shares at N = 2 / 4 / 8 as ONE-GPU launches
 # (what one rank of the strong-scaled job runs: 1/N of the 8.75 GiB batch, two streams below 4 GiB) — the kernel-side scaling loss
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
@@ -29,9 +31,11 @@ timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_sh
 # BASELINE.json configs[4] rehearsed the way the driver starts it (no launcher: bench.py starts its own ranks), eight ranks sharing this
 # box's one GPU over the stand-in RCCL (real RCCL refuses two ranks per device), weak and strong scaling
 export CRN_RCCL_LIB=$R/tests/harness/libfake_rccl_mp.so HIP_VISIBLE_DEVICES=0
-timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --epochs 3584 --cpu-epochs 0 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err
-timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --scaling strong --cpu-epochs 0 > $O/bench_8ranks_one_gpu_strong.json 2> $O/bench_8ranks_one_gpu_strong.err
-timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --mode scan --epochs 8960 --cpu-epochs 0 > $O/bench_8ranks_one_gpu_scan.json 2> $O/bench_8ranks_one_gpu_scan.err
+# (the N > 1 lines carry cpu_baseline: rank 0 measures it after the timed region with the default protocol)
+timeout 900 python3 bench.py --gpus 2 --steps 20 --warmup 5 --epochs 14336 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --epochs 3584 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --scaling strong > $O/bench_8ranks_one_gpu_strong.json 2> $O/bench_8ranks_one_gpu_strong.err
+timeout 900 python3 bench.py --gpus 8 --steps 20 --warmup 5 --mode scan --epochs 8960 > $O/bench_8ranks_one_gpu_scan.json 2> $O/bench_8ranks_one_gpu_scan.err
 unset CRN_RCCL_LIB HIP_VISIBLE_DEVICES
 timeout 900 python tools/gpu_welch_spans.py > $O/welch_spans.txt 2>&1
 timeout 900 python tests/soak_gpu.py 20000 > $O/soak.txt 2>&1
