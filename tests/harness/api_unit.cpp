@@ -536,6 +536,61 @@ static void test_side_paths() {
   REQUIRE(crn_sense_destroy(h) == CRN_OK);
 }
 
+// Round-5 hardening of the handle: the LDS budget comes from the device, updates refuse a capturing stream, more updates
+// in flight than staging slots do not corrupt anything, a windowed handle has its one dealt form.
+static void test_device_limits_and_updates() {
+  crn_cfg cfg;
+  crn_handle *h = nullptr;
+  const crn_out o = any_outputs();
+  // a device (or partition) with 64 KiB of LDS per workgroup: ten 512-point |X| frames need 70 KiB of slots -> no dealt form, the streaming kernel
+  g_fake_hip_lds_bytes = 64 * 1024;
+  REQUIRE(crn_cfg_reference(&cfg) == CRN_OK && crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 364, 0, &o, nullptr) == CRN_OK);
+  REQUIRE(crn::g_last_lds_budget == 64 * 1024 && g_last.deal_rounds == 0);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  g_fake_hip_lds_bytes = 160 * 1024;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 364, 0, &o, nullptr) == CRN_OK);
+  REQUIRE(crn::g_last_lds_budget == 160 * 1024 && g_last.deal_rounds == 2);      // ten frames over eight lane groups
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  // windowed handles: the periodic Hann in energy mode on whole frames has a dealt form, a table window and |X| mode have none
+  REQUIRE(crn_cfg_welch(&cfg, 1024, 8, 64) == CRN_OK && crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 1024, 0, &o, nullptr) == CRN_OK && g_last.deal_rounds == 2);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  cfg.window = CRN_WINDOW_BLACKMAN_HARRIS;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 1024, 0, &o, nullptr) == CRN_OK && g_last.deal_rounds == 0);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  cfg.window = CRN_WINDOW_HANN;
+  cfg.mode = CRN_MODE_REF_MAG;
+  REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 1024, 0, &o, nullptr) == CRN_OK && g_last.deal_rounds == 0);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+  // updates on a stream that is being captured into a hipGraph are refused before anything is enqueued; launches are not their business
+  REQUIRE(crn_cfg_energy_scaled(&cfg, 1024, 4.0f) == CRN_OK && crn_sense_create(&cfg, &h) == CRN_OK);
+  hipStream_t cap = nullptr, other = nullptr;
+  REQUIRE(hipStreamCreateWithFlags(&cap, 0) == hipSuccess && hipStreamCreateWithFlags(&other, 0) == hipSuccess);
+  g_fake_hip_capturing_stream.store(cap);
+  float thr[4] = {9.f, 8.f, 7.f, 6.f}, nf = 0.f, feats[2 * 4] = {1, 1, 1, 1, 1, 1, 1, 1};
+  REQUIRE(crn_sense_set_thresholds(h, thr, 4, cap) == CRN_ERR_STATE && std::strstr(crn_last_error(), "captured") != nullptr);
+  REQUIRE(crn_sense_reserve_noise_floor(h) == CRN_OK);
+  REQUIRE(crn_sense_calibrate_thresholds(h, feats, 2, 4.0f, &nf, cap) == CRN_ERR_STATE);
+  REQUIRE(crn_sense_set_thresholds(h, thr, 4, other) == CRN_OK);               // another stream: fine
+  REQUIRE(crn_sense_run_device(h, g_iq, 2, 1024, 0, &o, cap) == CRN_OK);       // a launch on the capturing stream: fine
+  g_fake_hip_capturing_stream.store(nullptr);
+  // 40 updates back to back, more than the 8 staging slots: every one lands, the last one's values are the table's
+  for (int i = 0; i < 40; i++) {
+    for (int b = 0; b < 4; b++) thr[b] = 100.f * i + b;
+    REQUIRE(crn_sense_set_thresholds(h, thr, 4, other) == CRN_OK);
+  }
+  REQUIRE(crn_sense_run_device(h, g_iq, 2, 1024, 0, &o, other) == CRN_OK);
+  REQUIRE(g_last.thresh[0] == 3900.f && g_last.thresh[3] == 3903.f);
+  REQUIRE(reinterpret_cast<const float *>(g_last.band_tab + 416)[2] == 3902.f);
+  (void)hipStreamDestroy(cap);
+  (void)hipStreamDestroy(other);
+  REQUIRE(crn_sense_destroy(h) == CRN_OK);
+}
+
 int main() {
   for (int N : {512, 1024, 2048, 4096}) {
     test_tables(N, true);
@@ -546,10 +601,11 @@ int main() {
   test_arguments_and_counters();
   test_run_host();
   test_side_paths();
+  test_device_limits_and_updates();
   if (g_failed) {
     std::fprintf(stderr, "api_unit: %d check(s) failed\n", g_failed);
     return 1;
   }
-  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates, host-buffer staging, side paths: ok\n");
+  std::printf("api_unit: tables (4 sizes x 2 plans), windows, launch geometry (5 CU counts x 4 sizes x 4 K x 21 batch sizes + Welch), arguments, live updates, host-buffer staging, side paths, device limits and update staging: ok\n");
   return 0;
 }

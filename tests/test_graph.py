@@ -70,3 +70,43 @@ def test_small_launches_captured_in_a_hip_graph(built):
     if out_dir and os.path.isdir(out_dir):
         open(os.path.join(out_dir, "hipgraph_small_launches.txt"), "w").write(line + "\n")
     s.close()
+
+
+def test_updates_are_refused_on_a_capturing_stream(built):
+    """crn_sense_set_thresholds / _set_ann / _calibrate_thresholds stage their values in a reused pinned slot and mark it with an event:
+    captured into a graph, the event would never complete for the host and every replay would upload whatever the slot holds by then.
+    They return CRN_ERR_STATE on a stream that is capturing and enqueue nothing — the capture itself is unharmed: the launches around
+    the refused update are in the graph and replay with the thresholds set OUTSIDE the capture."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = cs.cfg_energy_scaled(1024, 4.0)
+    E = 8
+    iq, _ = signals.make_epochs(cfg, E, seed=77)
+    buf = torch.from_numpy(iq).to(dev)
+    feat = torch.zeros(E, 4, device=dev)
+    occ = torch.zeros(E, 4, dtype=torch.uint8, device=dev)
+    outs = {"features": feat.data_ptr(), "ann_out": 0, "decision": 0, "occupancy": occ.data_ptr(), "spectrum": 0}
+    s = cs.Sensor(cfg)
+    side = torch.cuda.Stream(device=dev)
+    s.run_device(buf.data_ptr(), E, 1024, outs, stream=side.cuda_stream)
+    side.synchronize()
+    before = occ.clone()
+    assert int(before.sum()) > 0                          # the fixture's driven channels read occupied against lambda = 4
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        st = torch.cuda.current_stream().cuda_stream
+        with pytest.raises(cs.CrnError, match="captured"):
+            s.set_thresholds([float("inf")] * 4, stream=st)
+        w = np.zeros((5, 6)), np.zeros((6, 4))
+        assert cs.lib().crn_sense_set_ann(s._h, w[0].ctypes.data, w[1].ctypes.data, 0.8, st) != 0    # (refused: capture, then: not an ANN handle)
+        s.run_device(buf.data_ptr(), E, 1024, outs, stream=st)
+    occ.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(occ, before)                       # the refused update left the thresholds alone
+    s.set_thresholds([float("inf")] * 4, stream=side.cuda_stream)   # outside the capture: ordered on the stream, seen by the replay
+    side.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(occ.sum()) == 0
+    s.close()

@@ -23,7 +23,13 @@ int main(int argc, char **argv) {
   const int S = argc > 1 ? atoi(argv[1]) : 64;
   const int B = argc > 2 ? atoi(argv[2]) : 256;
   const double seconds = argc > 3 ? atof(argv[3]) : 3.0;
-  const bool sc16 = argc > 4 && strcmp(argv[4], "sc16") == 0;   // packets in the radio's wire format (int16 pairs)
+  // packets in the radio's wire format (int16 pairs): the optional entry points — build with -DCRN_WITH_SC16 against libcrnsense_sc16.so
+#ifdef CRN_WITH_SC16
+  const bool sc16 = argc > 4 && strcmp(argv[4], "sc16") == 0;
+#else
+  const bool sc16 = false;
+  if (argc > 4 && strcmp(argv[4], "sc16") == 0) { fprintf(stderr, "ring_rate: built without CRN_WITH_SC16\n"); return 2; }
+#endif
   const int L = 364;
   crn_cfg cfg;
   CHECK(crn_cfg_reference(&cfg));
@@ -31,7 +37,11 @@ int main(int argc, char **argv) {
   CHECK(crn_sense_create(&cfg, &h));
   CHECK(crn_sense_set_timing(h, 1));
   crn_ingest *g = NULL;
+#ifdef CRN_WITH_SC16
   CHECK(sc16 ? crn_ingest_create_sc16(h, S, L, B, &g) : crn_ingest_create(h, S, L, B, &g));
+#else
+  CHECK(crn_ingest_create(h, S, L, B, &g));
+#endif
   // a few MB of packet data, walked cyclically (so that the source is not one cache-resident packet)
   const int n_src = 4096;
   std::vector<float> src((size_t)n_src * L * 2);
@@ -48,7 +58,11 @@ int main(int argc, char **argv) {
   for (long long it = 0;; it++) {
     for (int s = 0; s < S; s++) {
       const size_t at = (size_t)((it * S + s) % n_src) * L * 2;
+#ifdef CRN_WITH_SC16
       const int rc = sc16 ? crn_ingest_push_sc16(g, s, src16.data() + at) : crn_ingest_push(g, s, src.data() + at);
+#else
+      const int rc = crn_ingest_push(g, s, src.data() + at);
+#endif
       if (rc == CRN_OK) pushed++;
       else if (rc == CRN_ERR_BUSY) refused++;
       else { fprintf(stderr, "push: %s\n", crn_last_error()); return 1; }
