@@ -1,6 +1,6 @@
 // crn_frame_ab.h — MEASUREMENT BUILD ONLY (libcrnsense_ab.so, -DCRN_AB_VARIANTS; included by crn_epoch_close.h).  What the shipped
 // library does not carry: the kTrace flag and the in-kernel time stamps of variant 17 (tools/gpu_wg_placement.py).  Every other
-// measurement variant that is still compiled (7, 19-22, 26, 27: crn_kernels.hip) is a combination of the shipped flags.  The schedules,
+// measurement variant that is still compiled (7, 19-22, 26, 27: crn_dispatch_ab.h) is a combination of the shipped flags.  The schedules,
 // ablations and layouts that were measured and not kept in rounds 1-4 (variants 1, 3-6, 8-12, 14-16, 18, 24, 25) were deleted in
 // round 5: docs/history/removed_variants.md names the commit that last held them.
 #ifndef CRN_FRAME_AB_H

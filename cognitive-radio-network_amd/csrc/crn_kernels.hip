@@ -24,52 +24,24 @@ namespace crn {
 
 // Kernel forms selectable through crn_sense_set_variant (0 = default).  The shipped library (libcrnsense.so) compiles the two that are
 // forms of the product — 13 (= 0, the default) and 2 (no pass-3 row pruning: what any band table outside the reference plan's rows runs
-// anyway) — and refuses the others.  libcrnsense_ab.so (-DCRN_AB_VARIANTS; tools/ and the A/B
-// test) adds the measurement forms that are combinations of the shipped flags (7, 19-22, 26, 27) and the trace build (17:
-// crn_frame_ab.h).  The numbers are the ones profiles/ and docs/history/ quote; the schedules, ablations and layouts of rounds 1-4
-// that were measured and not kept (1, 3-6, 8-12, 14-16, 18, 23-25) are gone from the tree: docs/history/removed_variants.md.
-struct VariantDesc { int nbuf, prefetch, nt, tw2lds, occ, pk; };   // nbuf == 0: no such form
-static constexpr VariantDesc kVariants[] = {
-    /* 0 (unused) */ {0, 0, 0, 0, 0, 0},
-    /* 1 */ {0, 0, 0, 0, 0, 0},
-    /* 2 */ {1, 1, 1, 1, 4, 1},   // the default without the pass-3 row pruning
-    /* 3 .. 6 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
-    /* 7 */ {1, 1, 1, 1, 4, 1},   // A/B: the default without the wave-priority raise in passes 1 and 2
-    /* 8 .. 12 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
-    /* 13 */ {1, 1, 1, 1, 4, 1},  // default: 4 workgroups/CU, compressed tw1, tw2 from LDS, row pruning when it applies
-    /* 14 .. 16 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
-    /* 17 */ {1, 1, 1, 1, 4, 1},  // A/B, measurement aid: the default + s_memtime stamps of the epoch close in ann_out
-    /* 18 */ {0, 0, 0, 0, 0, 0},
-    /* 19 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: Hann folded into pass 1's first butterflies
-    /* 20 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: 19 + pass-2 twiddles read from LDS ahead of their use (what ships)
-    /* 21 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: early pass-2 twiddle reads alone
-    /* 22 */ {1, 1, 1, 1, 3, 1},  // A/B, windowed kernels: the plain form (16 window registers, twiddles read where used)
-    /* 23 .. 25 */ {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0},
-    /* 26 */ {1, 1, 1, 0, 2, 1},  // A/B, windowed kernels: pass-2 twiddles in registers (no LDS twiddle reads) at 2 workgroups per CU
-    /* 27 */ {2, 1, 1, 0, 2, 1},  // A/B, windowed kernels: 26 + two exchange buffers (one barrier per frame)
-};
-static constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0])) - 1;
-static_assert(kNumVariants == 27, "variant numbers are the ones profiles/ and docs/ quote");
-static constexpr int kDefaultVariant = 13;
+// anyway) — and refuses every other number.  libcrnsense_ab.so (-DCRN_AB_VARIANTS; tools/ and the A/B test) adds measurement forms:
+// crn_dispatch_ab.h, the one seam in this file.  The numbers are the ones profiles/ and docs/history/ quote; the schedules, ablations
+// and layouts of rounds 1-4 that were measured and not kept are gone from the tree (docs/history/removed_variants.md).
+static constexpr int kNumVariants = 27, kDefaultVariant = 13;
+#ifdef CRN_AB_VARIANTS
+#include "crn_dispatch_ab.h"
+#else
+static bool measurement_variant(int) { return false; }           // no measurement forms in this build
+static bool measurement_variant_traces(int) { return false; }
+static void measurement_variant_desc(int, int *, int *) {}
+template <int R3>
+static bool launch_measurement_form(const SenseParams &, bool, bool, int, hipStream_t, hipError_t *) { return false; }
+#endif
 
 // Does this build of the library carry variant v?  (0 = default.)
-bool sense_variant_available(int v) {
-  if (v == 0 || v == kDefaultVariant || v == 2) return true;
-#ifdef CRN_AB_VARIANTS
-  return v == 7 || v == 17 || (v >= 19 && v <= 22) || v == 26 || v == 27;
-#else
-  return false;
-#endif
-}
+bool sense_variant_available(int v) { return v == 0 || v == kDefaultVariant || v == 2 || measurement_variant(v); }
 // ... and does it write time stamps over the ann_out buffer (so that the buffer must reach the kernel whatever the decision rule)?
-bool sense_variant_traces(int v) {
-#ifdef CRN_AB_VARIANTS
-  return v == 17;
-#else
-  (void)v;
-  return false;
-#endif
-}
+bool sense_variant_traces(int v) { return measurement_variant_traces(v); }
 
 // Wire-format input: crn_kernels_sc16.hip, linked only into a library built with `make SC16=1` (a weak reference: null when absent).
 __attribute__((weak)) hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream);
@@ -87,29 +59,7 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
       return launch_r<R3>(q, mag, win, variant, stream);
     }
   }
-#ifdef CRN_AB_VARIANTS   // measurement forms of the windowed kernels: combinations of the shipped flags
-  if constexpr (R3 == 16) {
-    if (win && !mag && p.hann_sym && p.L == Geo<R3>::N && (variant == 26 || variant == 27)) {
-      // the Welch kernel with its pass-2 twiddles in registers, 2 workgroups per CU: 26 one exchange buffer, 27 two
-      constexpr int kW = kBase | kHannSym;
-      const bool al = p.aligned_shift != 0;
-      if (variant == 26 && al) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, true, true, kW | kAlignedBands>>(p, stream);
-      if (variant == 26) return launch_cfg<Cfg<R3, 1, true, true, false, true, false, 2, true, true, kW>>(p, stream);
-      if (al) return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, true, true, kW | kAlignedBands>>(p, stream);
-      return launch_cfg<Cfg<R3, 2, true, true, false, true, false, 2, true, true, kW>>(p, stream);
-    }
-    if (variant == 17 && win && !mag && p.L == Geo<R3>::N)  // close stamps for the windowed / Welch kernel
-      return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kTrace>>(p, stream);
-  }
-  if (win && !mag && p.L == Geo<R3>::N && variant >= 19 && variant <= 22) {
-    // 19 Hann folded into pass 1 (needs a Hann handle), 20 = 19 + early pass-2 twiddle reads, 21 early twiddle reads alone, 22 the
-    // plain windowed kernel
-    if (variant == 19 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym>>(p, stream);
-    if (variant == 20 && p.hann_sym) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kHannSym | kTw2Early>>(p, stream);
-    if (variant == 21) return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase | kTw2Early>>(p, stream);
-    return launch_cfg<Cfg<R3, 1, true, true, false, true, true, 3, true, true, kBase>>(p, stream);
-  }
-#endif
+  if (hipError_t e; launch_measurement_form<R3>(p, mag, win, variant, stream, &e)) return e;   // (libcrnsense_ab.so only)
   // Periodic Hann (the Welch configuration), whole frames, energy mode: the window rides in pass 1's first
   // butterflies and the first block of pass-2 twiddles is read ahead of its use (+1 % on the Welch stream, and 8
   // window registers fewer; the A/B numbers are in docs/history/DESIGN_r03.md §5)
@@ -131,25 +81,13 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
   if (win) return launch_default<R3, 1, true, true, true, 3, true, kBase, 2>(p, mag, win, stream);
   if (R3 != 16 || mag || p.L != Geo<R3>::N) return launch_default<R3, 1, true, true, false, 3, true, kBase, 1, true, R3 != 16>(p, mag, win, stream);
   if constexpr (R3 == 16) {
-    if (!sense_variant_available(variant) || variant == 0) variant = kDefaultVariant;
-    constexpr int kPlain = kSpread | kLdsBlk | kTw1C | kMulti;
-    const bool regb = reg_bands(p), ref_rows = regb && (p.acc_mask & ~kRefPlanRows) == 0;
-    switch (variant) {
-      case 2:   // no pruning
-        if (regb) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu>(p, mag, win, stream);
-#ifdef CRN_AB_VARIANTS
-      case 7:   // the default without the wave-priority raise
-        if (ref_rows) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, true, kPlain>(p, mag, win, stream);
-      case 17:  // the default + time stamps
-        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kPrioValu | kRegBands | kTrace>(p, mag, win, stream);
-#endif
-      default:  // 13: the reference channel plan's rows only, unless the plan reaches others or the caller wants the per-bin spectrum
-        if (ref_rows) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kPrioValu | kRegBands>(p, mag, win, stream);
-        if (regb) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu | kRegBands>(p, mag, win, stream);
-        return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kPrioValu>(p, mag, win, stream);
-    }
+    constexpr int kPlain = kSpread | kLdsBlk | kTw1C | kMulti | kPrioValu;
+    const bool regb = reg_bands(p);
+    if (variant != 2 && regb && (p.acc_mask & ~kRefPlanRows) == 0)   // the reference channel plan's rows only (the default, 13)
+      return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRows | kRegBands>(p, mag, win, stream);
+    // another plan, a per-bin spectrum request, or variant 2: no pruning
+    if (regb) return launch_rn<R3, 1, true, true, true, 4, true, kPlain | kRegBands>(p, mag, win, stream);
+    return launch_rn<R3, 1, true, true, true, 4, true, kPlain>(p, mag, win, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -180,16 +118,10 @@ int sense_deal_rounds(int fft_len, bool mag, bool win, bool hann_whole_frames, i
 unsigned sense_ref_acc_mask(int fft_len) { return ref_acc_mask(fft_len / 256); }
 
 void sense_variant(int fft_len, int variant, int *nbuf, int *prefetch, int *nt, int *tw2lds, int *pk) {
-  if (variant < 0 || fft_len != 4096) {  // launch_default: every size / mode other than the 4096-pt plain path
-    *nbuf = 1; *prefetch = 1; *nt = 1; *tw2lds = 0; *pk = 1;
-    return;
-  }
-  if (variant == 0 || variant > kNumVariants || kVariants[variant].nbuf == 0) variant = kDefaultVariant;
-  *nbuf = kVariants[variant].nbuf;
-  *prefetch = kVariants[variant].prefetch;
-  *nt = kVariants[variant].nt;
-  *tw2lds = kVariants[variant].tw2lds;
-  *pk = kVariants[variant].pk;
+  *nbuf = 1; *prefetch = 1; *nt = 1; *pk = 1;
+  *tw2lds = (variant >= 0 && fft_len == 4096) ? 1 : 0;   // the plain 4096-point kernel reads its pass-2 twiddles from LDS (the other
+                                                         // sizes' plain kernels keep them in registers; windowed kernels: crn_api.cpp)
+  if (fft_len == 4096 && measurement_variant(variant)) measurement_variant_desc(variant, nbuf, tw2lds);
 }
 
 void sense_geometry(int fft_len, int variant, int *threads, int *lds_bytes, int *epochs_per_block) {

@@ -42,6 +42,8 @@ for seed in range(first, first + n_seeds):
     variant = int(rng.choice([0, 0, 0, 2, 7])) if n == 4096 else 0
     if cfg.window == 1 and cfg.mode == 1 and L == n and rng.random() < 0.5:
         variant = int(rng.choice([19, 20, 21, 22]))   # A/B set of the windowed kernel
+    if not cs.LIB_PATH.endswith("libcrnsense_ab.so") and variant not in (0, 2):
+        variant = 0                                   # (a library without the measurement forms: $CRN_SENSE_LIB)
     want_spec = bool(rng.random() < 0.5)
     n_epochs = int(rng.integers(1, 40))
     # Welch (hop N/2, windowed, whole frames) for a fifth of the windowed cases
@@ -119,12 +121,13 @@ for seed in range(first, first + n_seeds):
             ok = False
             why.append(f"spectrum: GPU vs float64 {eg:.3g}, oracle vs float64 {eo:.3g}")
     # wire format (int16 pairs) against the float path on the converted samples: bit for bit
-    if ok and variant == 0 and rng.random() < 0.3:
+    # (only a library with the optional wire-format kernels: $CRN_SENSE_LIB=.../libcrnsense_sc16.so; the measurement build has none)
+    if ok and variant == 0 and rng.random() < 0.3 and cs.has_sc16():
         raw = np.clip(np.round(iq * 32768.0 * 40.0), -32768, 32767).astype(np.int16)      # x 40: a few hundred levels of noise
         fl = raw.astype(np.float32) / np.float32(32768.0)
         d_raw, d_fl = torch.from_numpy(raw).cuda(), torch.from_numpy(fl).cuda()
         outs2 = []
-        for sc in ((False, True) if cs.has_sc16() else (False,)):   # wire format: only a library built with make SC16=1
+        for sc in (False, True):
             f_ = torch.zeros(n_epochs, cfg.n_bands, device="cuda")
             o_ = torch.zeros(n_epochs, cfg.n_bands, dtype=torch.uint8, device="cuda")
             d_ = torch.zeros(n_epochs, dtype=torch.int32, device="cuda")

@@ -4,8 +4,9 @@ reference's locking, packets paced at the radio's rate (364 samples / 13 Msps = 
 launcher thread idle in between.  Prints the engine's own counters (-s 1): kernel time and the time from the epoch's last packet to
 a readable decision — with the ring's pre-wake (the launcher thread is told ten packets ahead of the hand-off) and without it — and
 the distribution of execute()'s duration: its ten longest calls attributed (event, packet of the epoch, decision reported or not)
-next to a control (two clock reads with nothing between them: what the operating system does to the thread), over five runs of this
-build and, when ab/libcrnsense_r04.so exists, three of the round-4 library (LD_PRELOAD) for comparison.
+next to a control (two clock reads with nothing between them: what the operating system does to the thread), over five runs.
+(profiles/r05_engine_idle_gap_vs_r04_library.txt: the same with three runs of the round-4 library preloaded, taken before the ABI
+version moved to 4.)
 
     python3 tools/engine_idle_gap.py
 """
@@ -19,10 +20,7 @@ for ch in range(4):
     iq, _ = signals.make_epochs(cfg, 7, seed=900 + ch, L=L, picks=[ch] * 7)
     segs.append(iq[: per_seg * L * 2])
 np.concatenate(segs).tofile("/tmp/iq_gap.bin")
-r04 = os.path.join(os.getcwd(), "ab", "libcrnsense_r04.so")   # the round-4 library, when it was built beside (A/B: LD_PRELOAD)
 runs = [("this build, pre-wake on (default)", {})] * 5 + [("this build, pre-wake off (CRN_INGEST_PREWAKE_US=0)", {"CRN_INGEST_PREWAKE_US": "0"})] * 2
-if os.path.exists(r04):
-    runs += [("ROUND-4 LIBRARY (crn_ingest_poll takes the ring's mutex in every execute()), pre-wake on", {"LD_PRELOAD": r04})] * 3
 runs += [("this build, pre-wake without the empty warm-up launch (CRN_INGEST_WARM_GPU=0)", {"CRN_INGEST_WARM_GPU": "0"})]
 worst = {}
 for name, env in runs:
