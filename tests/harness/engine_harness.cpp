@@ -34,13 +34,17 @@ void CognitiveEngine::execute() { /* engines override this */ }
 
 static std::vector<float> g_exec_us;
 static std::vector<float> g_launch_us;  // the calls that took the K-th packet of an epoch (they enqueue the GPU work)
+static float g_control_max_us = 0.f;    // control: the longest gap between two clock reads with nothing between them (the OS alone)
 
 static void timed_execute(ExtensibleCognitiveRadio &ecr) {
-  struct timespec a, b;
+  struct timespec a, b, c;
   clock_gettime(CLOCK_MONOTONIC, &a);
   ecr.CE->execute();  // :1802
   clock_gettime(CLOCK_MONOTONIC, &b);
+  clock_gettime(CLOCK_MONOTONIC, &c);
   g_exec_us.push_back((float)((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3));
+  const float ctl = (float)((c.tv_sec - b.tv_sec) * 1e6 + (c.tv_nsec - b.tv_nsec) * 1e-3);
+  if (ctl > g_control_max_us) g_control_max_us = ctl;
 }
 
 static void print_new_epochs(ExtensibleCognitiveRadio &ecr, CE_Predictive_Node_GPU *engine, long *seen) {
@@ -159,6 +163,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < v.size(); i++) sum += v[i];
     printf("execute_us n %zu mean %.3f median %.3f p99 %.3f p999 %.3f max %.3f\n", v.size(), sum / v.size(),
            v[v.size() / 2], v[(size_t)(v.size() * 0.99)], v[(size_t)(v.size() * 0.999)], v.back());
+    printf("control_two_clock_reads_us max %.3f (nothing between the two reads: what the operating system alone does to this thread)\n", g_control_max_us);
   }
   std::sort(g_launch_us.begin(), g_launch_us.end());
   if (!g_launch_us.empty())

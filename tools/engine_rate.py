@@ -15,7 +15,7 @@ for name, mode in (("enqueue-only (default)", []), ("synchronous (-a 0)", ["-a",
     dec = np.array([int(l.split()[3]) for l in lines])
     print(f"engine {name}: {len(lines)} epochs, {(dec == picks[:len(dec)]).mean():.4f} correct, {dt:.2f} s wall incl. process start -> {len(lines) / dt:.0f} decisions/s ({len(lines) * 10 * L / dt / 1e6:.1f} Msamples/s; the radio delivers 13 Msamples/s)")
     for ln in out.stdout.splitlines():
-        if ln.startswith("execute_us") or ln.startswith("epoch_closing") or ln.startswith("CE_Predictive_Node_GPU:"):
+        if ln.startswith(("execute_us", "control_two_clock_reads_us", "epoch_closing", "CE_Predictive_Node_GPU:")):
             print("   ", ln)
 # the extension modes at the engine's default size (512 points): Welch estimate on the reference's channels, and the 64-band scan with
 # its start-up calibration — one epoch per launch as well (windowed, overlapped frames: the dealt-frame kernel's windowed forms)
