@@ -593,7 +593,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // half-frame is the previous span's last — so its spans are made long: ~256 frames per big workgroup while at least ~2.7
     // rounds of them remain over the 768 slots (3 workgroups per CU), a quarter of that per tail workgroup, one tail
     // workgroup per slot.  At K = 8 that is 32 epochs / 8 epochs / 6144 epochs: traffic 1.005 x the algorithmic bytes instead
-    // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r04_welch_spans.txt).
+    // of 1.033 x with 4-epoch spans and a single-epoch tail, and 1-2 % less time (profiles/r05_welch_spans.txt).
     if (c.window != CRN_WINDOW_RECT && c.hop * 2 == c.fft_len && epoch_stride == (int64_t)c.frames_per_epoch * c.hop) {
       const int64_t slots = slots3;
       epw = std::min<int64_t>(std::max<int64_t>(256 / c.frames_per_epoch, 1), n_groups * 3 / (8 * slots));   // >= 2.67 rounds of them
@@ -611,7 +611,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
     // A launch of a few epochs (the engine's: one) leaves most of every workgroup idle in the streaming kernel — an epoch is one lane
     // group running its K frames one after the other.  Up to one epoch per compute unit the dealt-frame kernel spreads an epoch's
     // frames over the lane groups of a workgroup of its own instead (csrc/crn_sense_kernel.h: sense_kernel_dealt; same results bit
-    // for bit).  Measured (profiles/r04_dealt_frames_ab.txt, us per launch, streaming -> dealt): 1 reference epoch 19.7 -> 10.0 from
+    // for bit).  Measured (profiles/r05_dealt_frames_ab.txt, us per launch, streaming -> dealt): 1 reference epoch 19.7 -> 10.0 from
     // HBM and 29.4 -> 15.4 from pinned host memory (the ring's launch); 256 epochs 20.3 -> 10.9; from 512 epochs on — two
     // workgroups per CU — the energy forms lose (17.5 -> 20.5), so the switch sits at one per CU.
     const int64_t deal_max = h->deal_max_epochs >= 0 ? h->deal_max_epochs : (int64_t)h->n_cus;

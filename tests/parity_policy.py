@@ -6,7 +6,7 @@ Per bin       |E - E64| <= bound * max(E64, 1e-3 * mean_k E64), E = the K-frame 
               bound = 1e-5 up to +30 dB of in-band SNR of the driven channel at every size; above that the error follows the
               carrier's amplitude (fp32 dynamic range next to a strong carrier, whatever the factorisation: the radix-2 CPU
               restatement is 1.3-2x further off) and the bound is the fitted line snr_bound() below
-              (measured table: tests/test_gpu_parity.py::test_per_bin_error_against_in_band_snr, profiles/r04_per_bin_error_vs_snr.txt).
+              (measured table: tests/test_gpu_parity.py::test_per_bin_error_against_in_band_snr, profiles/r05_per_bin_error_vs_snr.txt).
 Features      relative 1e-5 against the oracle.
 Decisions     identical to the oracle's for every epoch outside the measured disagreement band around the compare
               (CE_Predictive_Node.cpp:245-261 `>= 0.8`; the threshold plans' `feature > thr`): the GPU forms its fp32 features in
@@ -49,7 +49,7 @@ def in_band_snr_db(signal_rms, noise_power, band_bins, n):
     return 10.0 * math.log10(signal_rms ** 2 / (noise_power * band_bins / n))
 
 
-# ---- decisions: the measured disagreement band (tests/test_decision_band.py -> profiles/r04_decision_band.txt) -------------------
+# ---- decisions: the measured disagreement band (tests/test_decision_band.py -> profiles/r05_decision_band.txt) -------------------
 # Widest distance from the compare at which GPU and oracle were seen to disagree, over >= 10 000 amplitudes per channel swept
 # log-spaced through +-1e-4 (relative amplitude) of each crossing, on the MI355X boxes of round 4:
 # ANN 5.35e-7 / 2.30e-7 / 4.9e-8 for CH1 / CH2 / CH3 (max |O_gpu - O_cpu| 6.3e-7); thresholds 2.0-2.3e-7 at N = 1024, 2.3-3.6e-7 at N = 4096

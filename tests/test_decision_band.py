@@ -13,7 +13,7 @@ an epoch whose output lands that close to the compare can fall on the other side
       50 % overlap, 64 bands, absolute thresholds, dense epochs through the streaming kernel): the same around feature / thr = 1.
 
 and reports, per channel and size, the widest distance from the compare at which the two disagreed.  The table goes to
-$CRN_EVIDENCE_DIR/decision_band.txt (committed as profiles/r04_decision_band.txt); tests/parity_policy.py carries the measured widths
+$CRN_EVIDENCE_DIR/decision_band.txt (committed as profiles/r05_decision_band.txt); tests/parity_policy.py carries the measured widths
 and sets the margins every other decision test grants itself to 10x them.  Asserted here: every disagreement lies inside the
 recorded band x 3 (other boxes, other seeds), i.e. well inside the margin; outside the margin there is none.
 """

@@ -3,7 +3,7 @@
 Tolerances (DESIGN.md "Parity"):
   per-bin   |E - E64| <= 1e-5 * max(E64, floor * mean_k E64)   E = K-frame average per bin.
             BASELINE.md §2 / SURVEY.md §8(c) state floor = 1e-3.  Measured on the GPU as a function of the driven channel's
-            in-band SNR (test_per_bin_error_against_in_band_snr, profiles/r04_per_bin_error_vs_snr.txt): the HIP path meets
+            in-band SNR (test_per_bin_error_against_in_band_snr, profiles/r05_per_bin_error_vs_snr.txt): the HIP path meets
             1e-5 at that floor on idle epochs (4-5e-7) and on driven epochs up to +30 dB in-band SNR at EVERY size (<= 7.3e-6);
             above that the error follows the carrier's amplitude — fp32 dynamic range next to the carrier, whatever the
             factorisation (the radix-2 CPU restatement is 1.3-2x further off) — and is held to the fitted line
@@ -122,7 +122,7 @@ def test_per_bin_error_at_the_stated_floor(built):
 
 
 # The per-bin bar as a function of the driven channel's in-band SNR — and every other bar — is defined once, in tests/parity_policy.py
-# (smoke() and DESIGN.md §2 quote the same file).  Measured (profiles/r04_per_bin_error_vs_snr.txt, written by the test below from the
+# (smoke() and DESIGN.md §2 quote the same file).  Measured (profiles/r05_per_bin_error_vs_snr.txt, written by the test below from the
 # run itself): at +30 dB 4.3e-6 / 4.3e-6 / 7.3e-6 / 7.0e-6 for N = 512 / 1024 / 2048 / 4096; at +36 dB 9.1e-6 / 9.9e-6 / 1.3e-5 /
 # 1.2e-5; idle epochs 4-5e-7 at every size.
 SNR_SWEEP_DB = [None, 0, 6, 12, 18, 24, 30, 36]   # None = idle epochs (no carrier)
