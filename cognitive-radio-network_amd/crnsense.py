@@ -28,7 +28,7 @@ MODE_REF_MAG, MODE_ENERGY = 0, 1
 DECIDE_ANN, DECIDE_THRESHOLD, DECIDE_NONE = 0, 1, 2
 WINDOW_RECT, WINDOW_HANN, WINDOW_BLACKMAN_HARRIS = 0, 1, 2
 
-# the optional wire-format entry points (include/crn_sense.h, #ifdef CRN_WITH_SC16): only in a library built with make SC16=1
+# the optional wire-format entry points (include/crn_sense_sc16.h): only in a library built with make SC16=1
 SC16_EXPORTS = ["crn_sense_run_device_sc16", "crn_pack_sc16_device", "crn_sense_set_wire_full_scale", "crn_ingest_create_sc16", "crn_ingest_push_sc16"]
 
 # every symbol include/crn_sense.h declares unconditionally (tests check the library exports them all)

@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "../../include/crn_sense.h"
+#ifdef CRN_WITH_SC16
+#include "../../include/crn_sense_sc16.h"   // the optional wire-format entry points (libcrnsense_sc16.so)
+#endif
 #include "crn_internal.h"
 #include "crn_kernels.h"
 
@@ -683,7 +686,7 @@ int crn_sense_run_device_any(crn_handle *h, const void *d_iq, int32_t bytes_per_
   return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, bytes_per_sample == 4);
 }
 
-#ifdef CRN_WITH_SC16   // optional: wire-format input (make SC16=1 -> libcrnsense_sc16.so; include/crn_sense.h)
+#ifdef CRN_WITH_SC16   // optional: wire-format input (make SC16=1 -> libcrnsense_sc16.so; include/crn_sense_sc16.h)
 int crn_sense_run_device_sc16(crn_handle *h, const int16_t *d_iq, int64_t n_epochs, int32_t samples_per_frame,
                               int64_t epoch_stride, const crn_out *d_out, void *stream) {
   return run_device_impl(h, d_iq, n_epochs, samples_per_frame, epoch_stride, d_out, stream, true);

@@ -34,6 +34,9 @@
 #include <vector>
 
 #include "../../include/crn_sense.h"
+#ifdef CRN_WITH_SC16
+#include "../../include/crn_sense_sc16.h"   // the optional wire-format entry points (libcrnsense_sc16.so)
+#endif
 #include "crn_internal.h"
 
 #define HIP_TRY(expr)                                                                      \

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/crn_sense.h"
+#include "../../include/crn_sense_sc16.h"
 #include "../../cognitive-radio-network_amd/csrc/crn_kernels.h"
 
 std::atomic<long long> g_fake_gpu_latency_ns{0};

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>   // the stand-in under tests/harness/fake_hip
 
 #include "../../include/crn_sense.h"
+#include "../../include/crn_sense_sc16.h"   // (the stand-in library carries the optional wire-format entry points too)
 
 std::atomic<long long> g_fake_gpu_latency_ns(0);
 

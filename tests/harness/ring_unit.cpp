@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>   // the stand-in under tests/harness/fake_hip
 
 #include "../../include/crn_sense.h"
+#include "../../include/crn_sense_sc16.h"
 
 #include "fake_sense.h"
 

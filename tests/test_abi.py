@@ -16,26 +16,34 @@ def _declared(text):
     return set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", text))
 
 
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+
+
 def test_header_symbols_are_exported(built):
-    """libcrnsense.so exports exactly what include/crn_sense.h declares unconditionally; the block behind CRN_WITH_SC16 (the optional
-    wire-format input) is exported by a `make SC16=1` library — all five or none — and by nothing else."""
-    hdr = open(os.path.join(ROOT, "include", "crn_sense.h")).read()
-    a, b = hdr.index("#ifdef CRN_WITH_SC16"), hdr.index("#endif /* CRN_WITH_SC16 */")
-    optional, declared = _declared(hdr[a:b]), _declared(hdr[:a] + hdr[b:])
+    """Every include/*.h against the library that implements it: libcrnsense.so exports exactly what include/crn_sense.h declares (no
+    more: nothing undeclared leaks out of the product; no less); the optional libcrnsense_sc16.so (make SC16=1) and the test artefact
+    libcrnsense_plain.so export that plus exactly the five entry points of include/crn_sense_sc16.h; libcrnliquidfft.so exports
+    include/crn_liquid_fft.h's three."""
+    inc = os.path.join(ROOT, "include")
+    assert sorted(os.listdir(inc)) == ["crn_liquid_fft.h", "crn_sense.h", "crn_sense_sc16.h"]
+    hdr = open(os.path.join(inc, "crn_sense.h")).read()
+    assert "#if" not in hdr.replace("#ifndef CRN_SENSE_H", "").replace("#ifdef __cplusplus", "").replace("#if defined(__GNUC__)", "")   # no optional blocks
+    declared, optional = _declared(hdr), _declared(open(os.path.join(inc, "crn_sense_sc16.h")).read())
     assert declared == set(cs.EXPORTS), declared ^ set(cs.EXPORTS)
     assert optional == set(cs.SC16_EXPORTS), optional ^ set(cs.SC16_EXPORTS)
     L = cs.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert L.crn_abi_version() == cs.CRN_ABI_VERSION
-    out = subprocess.run(["nm", "-D", "--defined-only", cs.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     if not os.environ.get("CRN_SENSE_LIB"):
-        assert exported == declared, exported ^ declared        # nothing undeclared leaks out of the product, nothing optional is in it
-    for path in (cs.SC16_LIB_PATH, cs.PLAIN_LIB_PATH):          # the optional build and the test artefact: the product + the five
+        assert _exported(cs.LIB_PATH) == declared, _exported(cs.LIB_PATH) ^ declared
+    for path in (cs.SC16_LIB_PATH, cs.PLAIN_LIB_PATH):
         if os.path.exists(path):
-            out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
-            assert {ln.split()[-1] for ln in out.splitlines() if " T " in ln} == declared | optional, path
+            assert _exported(path) == declared | optional, path
+    liquid = set(re.findall(r"\b(fft_[a-z_]+)\s*\(", open(os.path.join(inc, "crn_liquid_fft.h")).read()))
+    assert liquid == {"fft_create_plan", "fft_execute", "fft_destroy_plan"} and liquid <= _exported(cs.LIQUID_SHIM_PATH)
 
 
 def test_engine_directory_is_self_contained(built):

@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "../include/crn_sense.h"
+#ifdef CRN_WITH_SC16
+#include "../include/crn_sense_sc16.h"
+#endif
 
 #define CHECK(x)                                                       \
   do {                                                                 \
