@@ -222,3 +222,12 @@ def test_wire_format_with_another_converter_constant(built, mode):
     if cfg.decide == cs.DECIDE_ANN:
         assert torch.equal(dec[0], dec[1])
     s.close()
+
+
+if not HAVE:
+    # Nothing of the above can run in this process; it runs in the child (test_wire_format_suite_on_the_optional_library).  Take the
+    # tests out of this process's collection instead of reporting 40-odd "skipped": a skip should mean something did not run anywhere.
+    for _name in [n for n in list(globals()) if n.startswith("test_") and n not in (
+            "test_default_library_has_no_wire_format_entry_points", "test_wire_format_host_checks_on_the_optional_library",
+            "test_wire_format_suite_on_the_optional_library")]:
+        del globals()[_name]
