@@ -264,3 +264,26 @@ def test_bench_a_hung_rank_ends_the_job_within_the_stage_timeout(built):
     assert p.returncode != 0 and not [ln for ln in out.splitlines() if ln.strip().startswith("{")], (p.returncode, out[-500:])
     assert took < 120, took      # stage timeout 20 s + the launcher's own 30 s grace before it kills the stopped rank
     assert not psutil.pid_exists(stopped) or psutil.Process(stopped).status() == psutil.STATUS_ZOMBIE
+
+
+def test_bench_two_real_rccl_ranks_on_one_gpu_are_refused_not_hung(built):
+    """The furthest real RCCL goes on a one-GPU box: two self-launched ranks, the unique id made by rank 0 through the C ABI and broadcast
+    over gloo, both ranks inside ncclCommInitRank talking to each other over RCCL's own bootstrap — where RCCL finds the same PCI device
+    twice and refuses ("invalid usage").  The failure must come back as a message naming the call and a non-zero exit of the parent
+    within seconds, no JSON line, no rank left behind: the N > 1 path fails fast with the real library too."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CRN_RCCL_LIB")}
+    env.update(HIP_VISIBLE_DEVICES="0")
+    from test_comm import _run_group
+    t0 = time.monotonic()
+    out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs", "256",
+                      "--cpu-epochs", "0", "--stage-timeout", "40"], 200, env, cwd=ROOT)
+    took = time.monotonic() - t0
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")], out.stdout[-500:]
+    assert "ncclCommInitRank" in out.stderr, out.stderr[-2000:]
+    assert took < 120, took
+    d = os.environ.get("CRN_EVIDENCE_DIR")
+    if d and os.path.isdir(d):
+        msg = [ln for ln in out.stderr.splitlines() if "ncclCommInitRank" in ln]
+        open(os.path.join(d, "two_real_rccl_ranks_one_gpu.txt"), "w").write(
+            f"bench.py --gpus 2 with the real RCCL on one GPU: exit {out.returncode} after {took:.1f} s, no JSON line\n" + "\n".join(msg[:4]) + "\n")

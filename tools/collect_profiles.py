@@ -33,7 +33,9 @@ for src, dst in (("stats/runc/*_kernel_stats.csv", f"{tag}_kernel_stats.csv"), (
                  ("engine_between_ecr_threads.txt", f"{tag}_engine_between_ecr_threads.txt"),
                  ("asm_filter_byte_equal.txt", f"{tag}_asm_filter_byte_equal.txt"),
                  ("bench_wire_format_optional_library.json", f"{tag}_bench_wire_format_optional_library.json"),
-                 ("bench_2ranks_one_gpu.json", f"{tag}_bench_two_ranks_one_gpu_stand_in_wire.json")):
+                 ("bench_2ranks_one_gpu.json", f"{tag}_bench_two_ranks_one_gpu_stand_in_wire.json"),
+                 ("two_real_rccl_ranks_one_gpu.txt", f"{tag}_two_real_rccl_ranks_one_gpu.txt"),
+                 ("hipgraph_small_launches.txt", f"{tag}_hipgraph_small_launches.txt")):
     m = sorted(glob.glob(os.path.join(SRC, src)), key=os.path.getmtime)
     if m:
         shutil.copy(m[-1], os.path.join(DST, dst))
