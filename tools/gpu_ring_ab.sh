@@ -1,3 +1,9 @@
+#!/bin/bash
+# Round 5: the ingest ring's host rate, this build against the round-4 library interleaved on one box, then the round's soaks and the GPU
+# suite + smoke of the final commit.  The round-4 library is not in the tree: build it from its commit into ab/ first —
+#   git worktree add /tmp/r04 ec570c8 && make -C /tmp/r04/cognitive-radio-network_amd/csrc -j4 objs &&
+#   hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o ab/libcrnsense_r04.so /tmp/r04/cognitive-radio-network_amd/csrc/obj/*.o -ldl
+# (ring_rate does not check the ABI version and uses nothing that changed between 3 and 4).  -> profiles/r05_ring_rate_vs_r04_library.txt
 O=gpurun_out/r05d; mkdir -p $O
 for rep in 1 2 3; do
   for lib in new r04; do
