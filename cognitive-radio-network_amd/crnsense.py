@@ -216,7 +216,10 @@ def lib():
 
 
 def has_sc16():
-    """Does the loaded library carry the optional wire-format kernels and entry points (a `make SC16=1` build)?"""
+    """Does the loaded library carry the optional wire-format kernels and entry points (a `make SC16=1` build)?  (False, not an error,
+    while the library has not been built yet: test modules ask at import time, before the fixture that builds it has run.)"""
+    if _lib is None and not os.path.exists(LIB_PATH):
+        return False
     return hasattr(lib(), "crn_sense_run_device_sc16")
 
 
