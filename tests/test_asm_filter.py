@@ -196,6 +196,41 @@ def test_build_script_filters_when_everything_is_as_recorded_and_falls_back_othe
     assert r.returncode != 0 and not (tmp_path / "bad.o").exists()
 
 
+def test_default_make_never_needs_the_assembly_listing_and_make_asm_survives_a_fallback(tmp_path):
+    """the listing `make asm` writes exists only where the filter ran.  (a) it is not part of the default build —
+    `make -n -B` of the default target names every recipe and none of them keeps or tests a listing; (b) `make asm` itself, on a unit
+    the script builds by plain hipcc (a compiler that is not on the expected-file's list), still succeeds: plain `hipcc -S` listing,
+    <listing>.how says so; (c) with the expected-file as recorded the listing is the filter's input and its output sits beside it."""
+    r = subprocess.run(["make", "-C", CSRC, "-n", "-B", "SC16=1", "_all"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "hipcc_kernels.sh" in r.stdout and "libcrnsense_plain.so" in r.stdout
+    assert "dev.s" not in r.stdout and "CRN_KEEP_ASM=" not in r.stdout and "test -s" not in r.stdout
+    tool = _this_toolchain()
+    src = tmp_path / "tiny.hip"
+    src.write_text(TINY)
+    exp = tmp_path / "expected"
+    exp.write_text("toolchain some other clang 99\nunit tiny.hip 1 0\n")
+    make = ["make", "-C", CSRC, "asm", f"ASM_SRC={src}", f"ASM_DIR={tmp_path / 'build'}"]
+    r = subprocess.run(make, capture_output=True, text=True, timeout=300, env=dict(os.environ, CRN_ASM_EXPECTED=str(exp)))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    listing = tmp_path / "build" / "tiny.hip.dev.s"
+    assert listing.stat().st_size > 0 and "v_pk_fma_f32" in listing.read_text()
+    assert (tmp_path / "build" / "tiny.hip.dev.s.how").read_text().startswith("plain:")
+    assert not (tmp_path / "build" / "tiny.hip.dev_filtered.s").exists() and "listing from plain hipcc -S" in r.stderr
+    # (c) as recorded: take the counts from a recording run, then the filtered route
+    rec = tmp_path / "units"
+    r, _, _ = _build_tiny(tmp_path, {"CRN_ASM_RECORD": str(rec), "CRN_ASM_EXPECTED": str(tmp_path / "none")},
+                          flags=("-fno-slp-vectorize", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-pthread", "--offload-compress"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    unit = rec.read_text().split()
+    src.write_text(TINY)
+    exp.write_text(f"toolchain {tool}\nunit tiny.hip {unit[2]} {unit[3]}\n")
+    r = subprocess.run(make, capture_output=True, text=True, timeout=300, env=dict(os.environ, CRN_ASM_EXPECTED=str(exp)))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert (tmp_path / "build" / "tiny.hip.dev.s.how").read_text().startswith("filtered:")
+    assert (tmp_path / "build" / "tiny.hip.dev_filtered.s").stat().st_size > 0
+
+
 def test_this_builds_units_were_filtered_as_recorded(built):
     """obj/<unit>.o.how (written by hipcc_kernels.sh; the object directories stay in the build container)."""
     units, tools = _expected()
