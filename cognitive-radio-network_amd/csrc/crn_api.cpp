@@ -659,8 +659,9 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
       HIP_TRY(hipEventRecord(h->t_start[slot], static_cast<hipStream_t>(stream)));
     }
   }
+  int deal_rounds_run = 0;   // the form really launched: 0 when the device refused the dealt form's LDS and the streaming kernel took it
   const hipError_t le = crn::launch_sense(p, c.fft_len, c.mode == CRN_MODE_REF_MAG, c.window != CRN_WINDOW_RECT, h->variant,
-                                          static_cast<hipStream_t>(stream), sc16);
+                                          static_cast<hipStream_t>(stream), sc16, &deal_rounds_run);
   if (slot >= 0) (void)hipEventRecord(h->t_stop[slot], static_cast<hipStream_t>(stream));   // also after a failed launch: the slot must complete
   if (le == hipErrorNotSupported && sc16)
     return crn::fail(CRN_ERR_ARG, "this library was built without the wire-format kernels (make -C csrc SC16=1 builds libcrnsense_sc16.so)");
@@ -668,7 +669,7 @@ static int run_device_impl(crn_handle *h, const void *d_iq, int64_t n_epochs, in
   // every input sample once: consecutive epochs closer together than an epoch is long (Welch) share their overlap
   const int64_t extent = (int64_t)(c.frames_per_epoch - 1) * frame_stride + (c.hop == c.fft_len ? samples_per_frame : c.fft_len);
   h->n_launches.fetch_add(1, std::memory_order_relaxed);
-  if (p.deal_rounds > 0) h->n_dealt.fetch_add(1, std::memory_order_relaxed);
+  if (deal_rounds_run > 0) h->n_dealt.fetch_add(1, std::memory_order_relaxed);
   h->n_epochs.fetch_add(n_epochs, std::memory_order_relaxed);
   h->n_samples.fetch_add((n_epochs - 1) * std::min(epoch_stride, extent) + extent, std::memory_order_relaxed);
   return CRN_OK;
@@ -829,7 +830,11 @@ int refuse_capture(hipStream_t st, const char *what) {
 
 // A pinned staging slot whose last copy has completed (`lk` = tables_mu, held).  Normally the first one tried; when all eight are still in
 // flight the lock is RELEASED while this thread waits for the oldest — a launch on another thread never waits for an update's copy.
-int take_update_slot(crn_handle *h, std::unique_lock<std::mutex> &lk, int *slot) {
+// *waited says that happened: whatever the caller checked under the lock before (the number of bands, the decision rule) may have been
+// changed by a crn_sense_set_bands on another thread in that window, and the caller checks it again before it writes anything.
+// (The event waited for may be re-recorded by another updater meanwhile: the wait is only a hint, the loop queries every slot afresh.)
+int take_update_slot(crn_handle *h, std::unique_lock<std::mutex> &lk, int *slot, bool *waited) {
+  *waited = false;
   for (;;) {
     for (int k = 0; k < crn_handle::kUpdateSlots; k++) {
       const int i = (int)((h->upd_next + k) % crn_handle::kUpdateSlots);
@@ -847,6 +852,7 @@ int take_update_slot(crn_handle *h, std::unique_lock<std::mutex> &lk, int *slot)
     lk.unlock();
     const hipError_t e = hipEventSynchronize(oldest);
     lk.lock();
+    *waited = true;
     if (e != hipSuccess) return crn::fail(CRN_ERR_DEVICE, std::string("hipEventSynchronize(update slot): ") + hipGetErrorString(e));
   }
 }
@@ -868,7 +874,11 @@ int bands_of(crn_handle *h) {
 
 int set_thresholds_locked(crn_handle *h, std::unique_lock<std::mutex> &lk, const float *thresh, int32_t n_bands, hipStream_t st) {
   int slot = 0;
-  if (int rc = take_update_slot(h, lk, &slot)) return rc;
+  bool waited = false;
+  if (int rc = take_update_slot(h, lk, &slot, &waited)) return rc;
+  // (the slot taken stays marked used with its last, completed, event: the next update takes it)
+  if (waited && n_bands != h->cfg.n_bands)
+    return crn::fail(CRN_ERR_STATE, "the band plan changed while this update waited for a staging slot: nothing was written (set the thresholds of the new plan)");
   std::memcpy(h->cfg.thresh, thresh, sizeof(float) * (size_t)n_bands);
   float *src = h->upd[slot].thresh;
   std::memcpy(src, h->cfg.thresh, sizeof(float) * CRN_MAX_BANDS);
@@ -949,7 +959,10 @@ int crn_sense_set_ann(crn_handle *h, const double w_ih[5][6], const double w_ho[
       if (!std::isfinite(w_ho[j][k])) return crn::fail(CRN_ERR_ARG, "non-finite weight");
   HIP_TRY(hipSetDevice(h->device));
   int slot = 0;
-  if (int rc = take_update_slot(h, lk, &slot)) return rc;
+  bool waited = false;
+  if (int rc = take_update_slot(h, lk, &slot, &waited)) return rc;
+  if (waited && h->cfg.decide != CRN_DECIDE_ANN)
+    return crn::fail(CRN_ERR_STATE, "crn_sense_set_ann: the handle's plan changed while this update waited for a staging slot: nothing was written");
   std::memcpy(h->cfg.ann_w_ih, w_ih, sizeof(h->cfg.ann_w_ih));
   std::memcpy(h->cfg.ann_w_ho, w_ho, sizeof(h->cfg.ann_w_ho));
   h->cfg.ann_threshold = threshold;   // rides in the launch parameters

@@ -82,8 +82,10 @@ struct SynthParams {
   float adc_scale;             // 0: off; 2^(adc_bits - 1): components rounded to multiples of 1 / adc_scale, clipped to [-1, 1)
 };
 
+// *deal_rounds_run (when asked for) = the form that was really launched: p.deal_rounds when the dealt-frame kernel took it, 0 when the
+// streaming kernel did — also when the device refused the dealt form's LDS and the launch fell back (crn_sense_dealt_launches counts from this)
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
-                        hipStream_t stream, bool sc16 = false);
+                        hipStream_t stream, bool sc16 = false, int *deal_rounds_run = nullptr);
 int sense_num_variants();
 // Rounds of dealt frames (ceil(K / lane groups)) when sense_kernel_dealt can take this size / mode / window / K — N <= 1024, no window or
 // the periodic Hann on whole frames in energy mode, and the frame slots fit in the device's LDS per workgroup (lds_budget_bytes:

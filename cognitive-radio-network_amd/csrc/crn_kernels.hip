@@ -44,19 +44,22 @@ bool sense_variant_available(int v) { return v == 0 || v == kDefaultVariant || v
 bool sense_variant_traces(int v) { return measurement_variant_traces(v); }
 
 // Wire-format input: crn_kernels_sc16.hip, linked only into a library built with `make SC16=1` (a weak reference: null when absent).
-__attribute__((weak)) hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream);
+__attribute__((weak)) hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream, int *deal_rounds_run);
 
 // The forms other than the default exist for N = 4096 only; other sizes always run the default.
 template <int R3>
-static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
+static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream, int *deal_rounds_run) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti;
   if constexpr (R3 <= 4) {   // a launch of a few epochs (crn_api.cpp sets deal_rounds): one epoch per workgroup, frames dealt to its lane groups
     if (p.deal_rounds > 0) {
       const hipError_t e = win ? launch_dealt_win<R3, 0>(p, stream) : launch_dealt<R3, 0>(p, mag, stream);
-      if (e != hipErrorLaunchOutOfResources) return e;
+      if (e != hipErrorLaunchOutOfResources) {
+        if (e == hipSuccess && deal_rounds_run) *deal_rounds_run = p.deal_rounds;
+        return e;
+      }
       SenseParams q = p;   // the device refused the LDS the frame slots need (crn_sense_kernel.h: launch_dealt_cfg): the streaming form takes it
       q.deal_rounds = 0;
-      return launch_r<R3>(q, mag, win, variant, stream);
+      return launch_r<R3>(q, mag, win, variant, stream, deal_rounds_run);
     }
   }
   if (hipError_t e; launch_measurement_form<R3>(p, mag, win, variant, stream, &e)) return e;   // (libcrnsense_ab.so only)
@@ -93,13 +96,14 @@ static hipError_t launch_r(const SenseParams &p, bool mag, bool win, int variant
 }
 
 hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant,
-                        hipStream_t stream, bool sc16) {
-  if (sc16) return launch_sense_sc16 ? launch_sense_sc16(p, fft_len, mag, win, variant, stream) : hipErrorNotSupported;
+                        hipStream_t stream, bool sc16, int *deal_rounds_run) {
+  if (deal_rounds_run) *deal_rounds_run = 0;
+  if (sc16) return launch_sense_sc16 ? launch_sense_sc16(p, fft_len, mag, win, variant, stream, deal_rounds_run) : hipErrorNotSupported;
   switch (fft_len) {
-    case 512: return launch_r<2>(p, mag, win, variant, stream);
-    case 1024: return launch_r<4>(p, mag, win, variant, stream);
-    case 2048: return launch_r<8>(p, mag, win, variant, stream);
-    case 4096: return launch_r<16>(p, mag, win, variant, stream);
+    case 512: return launch_r<2>(p, mag, win, variant, stream, deal_rounds_run);
+    case 1024: return launch_r<4>(p, mag, win, variant, stream, deal_rounds_run);
+    case 2048: return launch_r<8>(p, mag, win, variant, stream, deal_rounds_run);
+    case 4096: return launch_r<16>(p, mag, win, variant, stream, deal_rounds_run);
     default: return hipErrorInvalidValue;
   }
 }

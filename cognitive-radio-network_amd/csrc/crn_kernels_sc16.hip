@@ -8,15 +8,18 @@ namespace crn {
 // Wire-format input (kSc16): the default kernels of every size, mode and window, the plain 4096-point kernel's three forms, and the
 // Welch configuration's kernel (periodic Hann, whole frames, energy).
 template <int R3>
-static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream) {
+static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int variant, hipStream_t stream, int *deal_rounds_run) {
   constexpr int kBase = kSpread | kLdsBlk | kPrioValu | kMulti | kSc16;
   if constexpr (R3 <= 4) {   // a launch of a few epochs: frames dealt to the workgroup's lane groups (sense_kernel_dealt)
     if (p.deal_rounds > 0) {
       const hipError_t e = win ? launch_dealt_win<R3, kSc16>(p, stream) : launch_dealt<R3, kSc16>(p, mag, stream);
-      if (e != hipErrorLaunchOutOfResources) return e;
+      if (e != hipErrorLaunchOutOfResources) {
+        if (e == hipSuccess && deal_rounds_run) *deal_rounds_run = p.deal_rounds;
+        return e;
+      }
       SenseParams q = p;   // (the device refused the LDS the frame slots need: the streaming form)
       q.deal_rounds = 0;
-      return launch_r_sc16<R3>(q, mag, win, variant, stream);
+      return launch_r_sc16<R3>(q, mag, win, variant, stream, deal_rounds_run);
     }
   }
   if (win) {
@@ -39,12 +42,12 @@ static hipError_t launch_r_sc16(const SenseParams &p, bool mag, bool win, int va
   return launch_default<R3, 1, true, true, false, 3, true, kBase, 1, false, R3 != 16>(p, mag, win, stream);   // (no plan-specific pruning in wire format)
 }
 
-hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream) {
+hipError_t launch_sense_sc16(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t stream, int *deal_rounds_run) {
   switch (fft_len) {
-    case 512: return launch_r_sc16<2>(p, mag, win, variant, stream);
-    case 1024: return launch_r_sc16<4>(p, mag, win, variant, stream);
-    case 2048: return launch_r_sc16<8>(p, mag, win, variant, stream);
-    case 4096: return launch_r_sc16<16>(p, mag, win, variant, stream);
+    case 512: return launch_r_sc16<2>(p, mag, win, variant, stream, deal_rounds_run);
+    case 1024: return launch_r_sc16<4>(p, mag, win, variant, stream, deal_rounds_run);
+    case 2048: return launch_r_sc16<8>(p, mag, win, variant, stream, deal_rounds_run);
+    case 4096: return launch_r_sc16<16>(p, mag, win, variant, stream, deal_rounds_run);
     default: return hipErrorInvalidValue;
   }
 }

@@ -25,7 +25,8 @@ std::atomic<long long> g_fake_gpu_latency_ns{0};
 static std::atomic<long long> g_launches{0}, g_mixed{0}, g_plan_seen[2];
 
 namespace crn {
-hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipStream_t, bool) {
+hipError_t launch_sense(const SenseParams &p, int fft_len, bool, bool, int, hipStream_t, bool, int *deal_rounds_run) {
+  if (deal_rounds_run) *deal_rounds_run = p.deal_rounds;
   // the plan as a kernel would find it: band 1's first segment (lo, hi) from the packed table, the segment tables, the thresholds
   const int sb = p.band_tab[1];                       // band_seg_begin[1]
   const int lo = p.band_tab[96 + sb], hi = p.band_tab[256 + sb];

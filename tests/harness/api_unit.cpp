@@ -26,6 +26,7 @@ crn::SenseParams g_last;
 int g_last_fft = 0, g_last_variant = -1, g_launches = 0;
 bool g_last_mag = false, g_last_win = false, g_last_sc16 = false;
 bool g_write_pattern = false;
+bool g_refuse_dealt = false;   // the device refuses the dealt form's LDS: the real launch_sense falls back to the streaming kernel
 float g_iq_first = 0, g_iq_last = 0;
 crn::FftParams g_fft;
 crn::MonitorParams g_mon;
@@ -35,7 +36,8 @@ long long g_pack_n = 0;
 float g_pack_scale = 0;
 }  // namespace
 namespace crn {
-hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t, bool sc16) {
+hipError_t launch_sense(const SenseParams &p, int fft_len, bool mag, bool win, int variant, hipStream_t, bool sc16, int *deal_rounds_run) {
+  if (deal_rounds_run) *deal_rounds_run = g_refuse_dealt ? 0 : p.deal_rounds;   // (csrc/crn_kernels.hip: launch_r)
   if (g_write_pattern) {
     // what a launch reads and writes, touched at its ends (under AddressSanitizer a slab one byte short is a report) and filled
     // with values the caller can recognise after the copies back
@@ -553,6 +555,16 @@ static void test_device_limits_and_updates() {
   REQUIRE(crn_sense_create(&cfg, &h) == CRN_OK);
   REQUIRE(crn_sense_run_device(h, g_iq, 1, 364, 0, &o, nullptr) == CRN_OK);
   REQUIRE(crn::g_last_lds_budget == 160 * 1024 && g_last.deal_rounds == 2);      // ten frames over eight lane groups
+  // crn_sense_dealt_launches counts the form that RAN: a dealt launch the device refuses (hipErrorLaunchOutOfResources inside
+  // launch_sense, which then launches the streaming kernel) is a launch, not a dealt launch
+  int64_t n_dealt = 0;
+  REQUIRE(crn_sense_dealt_launches(h, &n_dealt) == CRN_OK && n_dealt == 1);
+  g_refuse_dealt = true;
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 364, 0, &o, nullptr) == CRN_OK && g_last.deal_rounds == 2);   // asked for ...
+  g_refuse_dealt = false;
+  REQUIRE(crn_sense_dealt_launches(h, &n_dealt) == CRN_OK && n_dealt == 1);                              // ... but not what ran
+  REQUIRE(crn_sense_run_device(h, g_iq, 1, 364, 0, &o, nullptr) == CRN_OK);
+  REQUIRE(crn_sense_dealt_launches(h, &n_dealt) == CRN_OK && n_dealt == 2);
   REQUIRE(crn_sense_destroy(h) == CRN_OK);
   // windowed handles: the periodic Hann in energy mode on whole frames has a dealt form, a table window and |X| mode have none
   REQUIRE(crn_cfg_welch(&cfg, 1024, 8, 64) == CRN_OK && crn_sense_create(&cfg, &h) == CRN_OK);
@@ -587,6 +599,28 @@ static void test_device_limits_and_updates() {
   REQUIRE(crn_sense_run_device(h, g_iq, 2, 1024, 0, &o, other) == CRN_OK);
   REQUIRE(g_last.thresh[0] == 3900.f && g_last.thresh[3] == 3903.f);
   REQUIRE(reinterpret_cast<const float *>(g_last.band_tab + 416)[2] == 3902.f);
+  // all eight staging slots in flight, so the ninth update lets go of the tables' lock while it waits for the oldest — and in
+  // that window another thread's crn_sense_set_bands swaps the plan for one of three bands.  The update must notice (CRN_ERR_STATE) and
+  // write nothing: the new plan keeps the thresholds it came with.
+  g_fake_gpu_latency_ns.store(30 * 1000 * 1000);
+  for (int i = 0; i < 8; i++) REQUIRE(crn_sense_set_thresholds(h, thr, 4, other) == CRN_OK);
+  static crn_handle *s_h;
+  static int s_rc;
+  s_h = h;
+  s_rc = -1;
+  g_fake_hip_on_event_sync = [] {
+    g_fake_hip_on_event_sync = nullptr;
+    const crn_band_seg segs[3] = {{8, 24, 0}, {40, 72, 1}, {100, 140, 2}};
+    const float t3[3] = {11.f, 12.f, 13.f};
+    s_rc = crn_sense_set_bands(s_h, segs, 3, 3, t3);
+  };
+  for (int b = 0; b < 4; b++) thr[b] = 7000.f + b;
+  REQUIRE(crn_sense_set_thresholds(h, thr, 4, other) == CRN_ERR_STATE && std::strstr(crn_last_error(), "band plan changed") != nullptr);
+  REQUIRE(s_rc == CRN_OK && g_fake_hip_on_event_sync == nullptr);
+  g_fake_gpu_latency_ns.store(0);
+  REQUIRE(crn_sense_run_device(h, g_iq, 2, 1024, 0, &o, other) == CRN_OK);
+  REQUIRE(g_last.n_bands == 3 && g_last.thresh[0] == 11.f && g_last.thresh[2] == 13.f);
+  REQUIRE(reinterpret_cast<const float *>(g_last.band_tab + 416)[1] == 12.f);
   (void)hipStreamDestroy(cap);
   (void)hipStreamDestroy(other);
   REQUIRE(crn_sense_destroy(h) == CRN_OK);

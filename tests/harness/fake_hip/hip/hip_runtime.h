@@ -52,8 +52,10 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { fake_hip_no
 inline hipError_t hipEventDestroy(hipEvent_t e) { fake_hip_note(); delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { fake_hip_note(); e->ready_at_ns.store(fake_hip_now_ns() + g_fake_gpu_latency_ns.load()); return hipSuccess; }
 inline hipError_t hipEventQuery(hipEvent_t e) { fake_hip_note(); return fake_hip_now_ns() >= e->ready_at_ns.load() ? hipSuccess : hipErrorNotReady; }
+inline void (*g_fake_hip_on_event_sync)() = nullptr;   // a test's hook: runs inside the wait, i.e. while the caller holds no lock of its own
 inline hipError_t hipEventSynchronize(hipEvent_t e) {
   fake_hip_note(true);
+  if (g_fake_hip_on_event_sync) g_fake_hip_on_event_sync();
   const bool w = fake_hip_watch_thread;
   fake_hip_watch_thread = false;   // (the polling below is this wait, not further calls)
   struct Restore { bool w; ~Restore() { fake_hip_watch_thread = w; } } restore{w};

@@ -22,7 +22,10 @@ needs_sc16 = pytest.mark.skipif(not HAVE, reason="the loaded library was built w
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _child_suite(marker):
+def _child_suite(marker, at_least):
+    """Runs this file (and the wire-format dealt-frame test) in a child process against libcrnsense_sc16.so.  ADVICE r05: the parent's
+    "1 passed" must stand for the whole child suite — so the child's own count is asserted (>= at_least, none skipped) and, on an
+    evidence pass ($CRN_EVIDENCE_DIR), its last line is kept under profiles/."""
     if HAVE:
         pytest.skip("already running against a library with the wire-format kernels")
     if not os.path.exists(cs.SC16_LIB_PATH):
@@ -32,6 +35,12 @@ def _child_suite(marker):
                        cwd=ROOT, env=dict(os.environ, CRN_SENSE_LIB=cs.SC16_LIB_PATH), capture_output=True, text=True, timeout=1500)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0 and " passed" in tail and "skipped" not in tail, r.stdout[-3000:] + r.stderr[-2000:]
+    n_passed = int(tail.split(" passed")[0].split()[-1])
+    assert n_passed >= at_least, f"the child suite ran {n_passed} tests, expected at least {at_least}: {tail}"
+    d = os.environ.get("CRN_EVIDENCE_DIR")
+    if d and os.path.isdir(d):
+        with open(os.path.join(d, f"wire_format_child_suite_{marker.replace(' ', '_')}.txt"), "w") as f:
+            f.write(f"pytest -m '{marker}' tests/test_sc16.py + test_dealt_frames_in_the_wire_format with CRN_SENSE_LIB=libcrnsense_sc16.so (child process):\n{tail}\n")
     return tail
 
 
@@ -47,12 +56,12 @@ def test_default_library_has_no_wire_format_entry_points(built):
 
 
 def test_wire_format_host_checks_on_the_optional_library(built):
-    print(_child_suite("not gpu"))
+    print(_child_suite("not gpu", 1))
 
 
 @pytest.mark.gpu
 def test_wire_format_suite_on_the_optional_library(built):
-    print(_child_suite("gpu"))
+    print(_child_suite("gpu", 44))
 
 
 @needs_sc16
