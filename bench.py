@@ -79,6 +79,47 @@ def usable_cores():
     return n, why
 
 
+# What a failing rank at N > 1 says about itself (fail_report): filled in as main() goes along, readable from the watchdog thread
+# without any GPU call (a hung main thread may be inside one).
+RUN = {"stage": "start", "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "t0": time.monotonic(),
+       "multi": False, "rccl": None, "pci_bus_id": None, "device": None, "devices_seen": None}
+
+
+def visible_devices():
+    """What the process was allowed to see: the isolation variables a launcher may have set, and how many devices HIP then shows."""
+    v = {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL") if k in os.environ}
+    v["device_count"] = RUN["devices_seen"]
+    v["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    return v
+
+
+def fail_report(why, stage=None):
+    """ONE JSON object on stderr per failing rank of an N > 1 job (or of the one-GPU rehearsal of that path), so that the launcher's
+    tail names the cause — device isolation, RCCL bootstrap, IPC mode, a hung peer — the first time an 8-GPU node runs this:
+    {"bench_failure": {"failed_stage", "rank", "world", "elapsed_s", "why", "rccl": crn_comm_info or null, "visible_devices",
+    "pci_bus_id", "device"}}.  Uses only what main() cached: no GPU call is made here."""
+    if not (RUN["world"] > 1 or RUN["multi"]) or RUN.get("reported"):
+        return
+    RUN["reported"] = True   # one object per rank: a gloo timeout on the main thread and the watchdog can fire within the same second
+    obj = {"bench_failure": {"failed_stage": stage or RUN["stage"], "rank": RUN["rank"], "world": RUN["world"],
+                             "elapsed_s": round(time.monotonic() - RUN["t0"], 3), "why": str(why)[:600], "rccl": RUN["rccl"],
+                             "visible_devices": visible_devices(), "pci_bus_id": RUN["pci_bus_id"], "device": RUN["device"]}}
+    try:
+        os.write(2, (json.dumps(obj) + "\n").encode())   # one write: lines of several ranks do not interleave
+    except OSError:
+        pass
+
+
+def pci_bus_id_of(torch, index):
+    """PCI address of HIP device `index` ("0000:c5:00.0") before any communicator exists, from torch's device properties (the same three
+    numbers hipDeviceGetPCIBusId prints; crn_comm_info's own string replaces it once RCCL has bound the rank); None when unavailable."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:   # noqa: BLE001
+        return None
+
+
 class Watchdog:
     """N > 1 only: every rank must pass from one stage of the run to the next within `limit` seconds.  gloo's own timeout covers its
     collectives; this covers what it cannot see — a rank stuck inside ncclCommInitRank, or in a device synchronise behind an
@@ -93,6 +134,7 @@ class Watchdog:
 
     def pet(self, stage):
         self.stage, self.t = stage, time.monotonic()
+        RUN["stage"] = stage
 
     def stop(self):
         self.done = True
@@ -103,6 +145,8 @@ class Watchdog:
             if not self.done and time.monotonic() - self.t > self.limit:
                 print(f"bench.py: rank {self.rank}: stage '{self.stage}' did not finish within {self.limit:.0f} s (a peer hung or died?): "
                       "exiting 6 so that the launcher stops the job", file=sys.stderr, flush=True)
+                fail_report(f"watchdog: stage did not finish within {self.limit:.0f} s (a peer hung or died, or this rank is stuck in "
+                            "native code)", self.stage)
                 os._exit(6)
 
 
@@ -285,6 +329,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_collective
+    RUN.update(rank=rank, world=world, multi=multi, device=local_rank, devices_seen=torch.cuda.device_count(),
+               pci_bus_id=pci_bus_id_of(torch, local_rank))
     dog = None
     if world > 1:
         import datetime
@@ -296,6 +342,7 @@ def main():
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.stage_timeout))
 
     def stage(name):
+        RUN["stage"] = name
         if dog is not None:
             dog.pet(name)
     stage("set-up")
@@ -401,6 +448,9 @@ def main():
     # (two streams: four slots, so that a stream's next launch never waits for the gather of its previous one)
     stage("communicator (ncclCommInitRank is collective)")
     ex, ex_kind = make_device_exchange(E, cfg.n_bands, local_rank, rank, world, depth=4 if two_streams else 2) if multi else (None, "")
+    if ex is not None:
+        RUN["rccl"] = ex.info()   # (cached: a failure report must not call into RCCL from beside a hung main thread)
+        RUN["pci_bus_id"] = RUN["rccl"].get("pci_bus_id") or RUN["pci_bus_id"]
     torch.cuda.synchronize()   # the set-up above ran on the current stream; the timed launches may run on others
     stage("warm-up")
     n_done = 0
@@ -711,7 +761,8 @@ def main():
     # ---- N > 1: what every rank measured and what RCCL itself says the communicator is ------------------
     rccl, per_rank = None, None
     if ex is not None:
-        mine = {"rank": rank, "device": local_rank, "kernel_ms_mean": kern_ms_mean, "frac": achieved / HBM_PEAK_GBS, "comm": ex.info()}
+        mine = {"rank": rank, "device": local_rank, "kernel_ms_mean": kern_ms_mean, "frac": achieved / HBM_PEAK_GBS, "comm": ex.info(),
+                "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "all"))}
         everyone = [mine]
         if world > 1:
             everyone = [None] * world
@@ -729,8 +780,13 @@ def main():
             raise SystemExit(f"bench: the communicator is not the {world} ranks of this job: {rccl}")
         # N ranks on N different GPUs: real RCCL refuses two ranks per device, and the line must show it did not have to — every rank names
         # another physical device (a stand-in library, version 0, shares one GPU between the ranks by design: tests only)
-        if rccl["version"] != 0 and len(set(rccl["pci_bus_ids"])) != world:
-            raise SystemExit(f"bench: {world} ranks but {len(set(rccl['pci_bus_ids']))} distinct GPUs: {rccl['pci_bus_ids']}")
+        # (a rank whose hipDeviceGetPCIBusId failed reports "": unknown, not "the same device" — ADVICE r05.  It then vouches for its
+        # device by what RCCL bound it to plus what the launcher let it see; real RCCL has itself refused two ranks on one device.)
+        where = [b or f"unknown-pci:rccl_device={dv}:visible={vis}" for b, dv, vis in zip(rccl["pci_bus_ids"], rccl["devices"], [r["visible"] for r in everyone])]
+        if "" in rccl["pci_bus_ids"]:
+            rccl["pci_bus_ids_note"] = "hipDeviceGetPCIBusId failed on some rank(s): those are told apart by (RCCL device ordinal, visible-device list)"
+        if rccl["version"] != 0 and len(set(where)) != world:
+            raise SystemExit(f"bench: {world} ranks but {len(set(where))} distinct GPUs: {where}")
         slow = max(everyone, key=lambda r: r["kernel_ms_mean"])
         fast = min(everyone, key=lambda r: r["kernel_ms_mean"])
         per_rank = {"kernel_ms_mean": [r["kernel_ms_mean"] for r in everyone], "kernel_ms_mean_min": fast["kernel_ms_mean"],
@@ -746,7 +802,13 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "fft_len": N, "frames_per_epoch": K, "epochs_per_gpu": E,
-                       "epochs_per_step_all_gpus": E * world, "bytes_per_gpu_per_step": algo_bytes, "kernel": info["name"],
+                       "epochs_per_step_all_gpus": E * world, "bytes_per_gpu_per_step": algo_bytes,
+                       # the headline's three conditions as fields (the workload text is long and gets cut): the batch is 4.4x SURVEY §8(d)
+                       # cfgH's 2 GiB; the kernel keeps n of 16 pass-3 rows (the reference channel plan; null = no pruning); and what the
+                       # same kernel reaches on cfgH's batch as worded (= alt.cfgH_2GiB_batch.frac; null when that leg did not run)
+                       "batch_GiB": round(algo_bytes / 2 ** 30, 4), "pruned_rows": f"{n_kept}/16" if pruned else None,
+                       "cfgH_as_worded_frac": alt["cfgH_2GiB_batch"]["frac"] if alt else None,
+                       "kernel": info["name"],
                        "parallelism": f"stream-sharded x{world}" + (", " + ex_kind if multi else ""),
                        "streams_per_gpu": len(tstreams),
                        **({"rccl": rccl} if rccl else {}),
@@ -777,4 +839,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit as e:
+        if e.code not in (0, None):
+            fail_report(e.code if isinstance(e.code, str) else f"exit {e.code}: {getattr(e, 'crn_reason', 'see the message above')}")
+        raise
+    except BaseException as e:   # noqa: BLE001 — reported, then re-raised unchanged
+        fail_report(f"{type(e).__name__}: {e}")
+        raise

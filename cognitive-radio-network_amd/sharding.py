@@ -84,9 +84,11 @@ def make_device_exchange(epochs, n_bands, device_index, rank, world, depth=2):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         all_ok = int(flag.item())
     if not all_ok:
-        print(f"sharding: rank {rank}: " + (f"RCCL is not usable through crn_comm_* here ({why[:300]})" if not ok else
-                                            "another rank cannot load RCCL through crn_comm_*") + ": stopping (exit 3)", file=sys.stderr)
-        raise SystemExit(3)
+        msg = (f"RCCL is not usable through crn_comm_* here ({why[:300]})" if not ok else "another rank cannot load RCCL through crn_comm_*")
+        print(f"sharding: rank {rank}: " + msg + ": stopping (exit 3)", file=sys.stderr)
+        stop = SystemExit(3)
+        stop.crn_reason = msg       # (bench.py's failure report quotes it)
+        raise stop
     return (DeviceOccupancyExchange(epochs, n_bands, device_index, rank, world, depth),
             "RCCL all-gather of occupancy (crn_comm_*, side stream)")
 

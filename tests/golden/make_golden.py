@@ -14,6 +14,18 @@ Inputs are seeded synthetic IQ (tests/signals.py: SURVEY.md §8(d) recipe).  Eve
 to sit outside the margin band (|O - 0.8| > 1e-3, |F / thr - 1| > 1e-4) so that fp32
 implementations can be required to reproduce the decisions exactly.
 
+Two kinds of epoch fixture:
+  * SEEDED (every BASELINE.json configuration at its own size): the file holds (seed, L, n_epochs, picks)
+    and the float64 outputs — features, network outputs, decisions, occupancy, margins, and the K-frame
+    spectrum on 64 chosen bins (the strongest 16 + 48 evenly spaced; `spectrum_bins`) with its per-epoch
+    mean over ALL bins for the error floor.  The test regenerates the IQ with signals.make_epochs (numpy
+    PCG64 + float64 tones: reproducible) and checks its energy against `iq_l2`.  A few KB per fixture, so
+    the headline configuration carries 8 epochs (idle + each channel, twice) and configs[2] exists at
+    4096 points.
+  * ONE IQ-CARRYING fixture (ref512_L364.npz: the reference engine's own configuration on the radio's
+    364-sample packets): the guard against a change of the generator itself — tests/test_golden.py asserts
+    that make_epochs still reproduces its samples — and what smoke() reads on the GPU box.
+
   python tests/golden/make_golden.py        (from the repo root, after __graft_entry__.build())
 """
 import json
@@ -45,16 +57,51 @@ def epochs_fixture(cfg, plan, n_epochs, seed, L, name, thresh=None):
                         decision=want["decision"], occupancy=want["occupancy"], margin=want["margin"], **extra)
 
 
-def welch_fixture(name, n=1024, k=8, n_bands=64, n_epochs=2, seed=0xC0FFEE + 3, lam=4.0):
-    """BASELINE.json configs[2] in small: Hann, 50 % overlap, 64 bands, thr_b = lam * median band energy
-    (SURVEY.md §8(d) cfg2), thresholds stored as the f32 array both implementations are handed."""
-    cfg = cs.cfg_welch(n, k, n_bands)
-    iq, _ = signals.make_epochs(cfg, n_epochs, seed=seed, L=n)
-    probe = ref_f64.run(ref_f64.plan_welch(n, k, n_bands, [np.inf] * n_bands), iq, n_epochs, L=n)
-    thr = np.full(n_bands, lam * np.median(probe["features"]), dtype=np.float32)
+def spectrum_bins(spec, n_sel=64, n_top=16):
+    """The bins a seeded fixture keeps: the n_top strongest of the epoch-mean spectrum (the tones) and evenly spaced ones up to n_sel."""
+    top = np.argsort(spec.mean(axis=0))[::-1][:n_top]
+    grid = np.arange(n_sel) * (spec.shape[1] // n_sel) + spec.shape[1] // (2 * n_sel)
+    bins = list(dict.fromkeys([int(b) for b in top] + [int(b) for b in grid]))[:n_sel]
+    return np.array(sorted(bins), dtype=np.int32)
+
+
+def seeded_fixture(cfg, plan, picks, seed, L, name, thresh=None, cfg_name=""):
+    """Writes the float64 outputs and the recipe of the input, not the input: see the module docstring."""
+    picks = np.asarray(picks, dtype=np.int32)
+    n_epochs = picks.size
+    iq, _ = signals.make_epochs(cfg, n_epochs, seed=seed, L=L, picks=picks)
+    want = ref_f64.run(plan, iq, n_epochs, L=L)
+    if plan.decide == "ann":
+        assert (want["margin"] > 1e-3).all(), (name, want["margin"])
+        assert (want["decision"] == picks).all(), (name, want["decision"], picks)
+    elif plan.decide == "threshold":
+        assert (want["margin"] > 1e-4).all(), (name, want["margin"])
+    bins = spectrum_bins(want["spectrum"])
+    extra = {} if thresh is None else {"thresh": np.asarray(thresh, np.float32)}
+    np.savez_compressed(os.path.join(HERE, name), cfg_name=np.str_(cfg_name), seed=np.int64(seed), L=np.int32(L), n_epochs=np.int32(n_epochs),
+                        picks=picks, iq_l2=np.float64(np.sum(iq.astype(np.float64) ** 2)),
+                        spectrum_bins=bins, spectrum_sel_f64=want["spectrum"][:, bins], spectrum_mean_f64=want["spectrum"].mean(axis=1),
+                        features_f64=want["features"], ann_out_f64=want["ann_out"],
+                        decision=want["decision"], occupancy=want["occupancy"], margin=want["margin"], **extra)
+    return want
+
+
+def welch_seeded(name, n, k=8, n_bands=64, picks=(0, 1, 2, 3), seed=0xC0FFEE + 3, lam=4.0):
+    """BASELINE.json configs[2] (n = 4096: as worded in SURVEY.md §8(d) cfg2; n = 1024: the small twin): Hann, 50 % overlap, hop n/2,
+    K = 8, 64 equal bands, thr_b = lam * median band energy of the batch, stored as the f32 array both implementations are handed.
+    The first seed at or after `seed` whose every (epoch, band) sits outside the margin band is taken and recorded."""
+    for sd in range(seed, seed + 64):
+        cfg = cs.cfg_welch(n, k, n_bands)
+        iq, _ = signals.make_epochs(cfg, len(picks), seed=sd, L=n, picks=np.asarray(picks))
+        probe = ref_f64.run(ref_f64.plan_welch(n, k, n_bands, [np.inf] * n_bands), iq, len(picks), L=n)
+        thr = np.full(n_bands, lam * np.median(probe["features"]), dtype=np.float32)
+        if (ref_f64.run(ref_f64.plan_welch(n, k, n_bands, thr), iq, len(picks), L=n)["margin"] > 1e-4).all():
+            break
+    else:
+        raise SystemExit(f"{name}: no seed in [{seed}, {seed + 64}) keeps every band outside the margin band")
     for b in range(n_bands):
         cfg.thresh[b] = float(thr[b])
-    epochs_fixture(cfg, ref_f64.plan_welch(n, k, n_bands, thr), n_epochs, seed, n, name, thresh=thr)
+    seeded_fixture(cfg, ref_f64.plan_welch(n, k, n_bands, thr), picks, sd, n, name, thresh=thr, cfg_name=f"welch{n}")
 
 
 def ann_fixture():
@@ -100,11 +147,19 @@ def kat_fixture():
 
 
 if __name__ == "__main__":
+    cycle = (0, 1, 2, 3, 3, 2, 1, 0)     # idle and each channel, twice: every occupancy state of the cascade
+    # the one fixture that carries its IQ (generator guard, smoke())
     epochs_fixture(cs.cfg_reference(), ref_f64.plan_reference(), 8, 0xC0FFEE, 364, "ref512_L364.npz")
-    epochs_fixture(cs.cfg_reference(), ref_f64.plan_reference(), 4, 0xC0FFEE + 4, 512, "ref512_L512.npz")
-    epochs_fixture(cs.cfg_energy_scaled(1024, 4.0), ref_f64.plan_energy_scaled(1024, 4.0), 3, 0xC0FFEE + 1, 1024, "energy1024.npz")
-    epochs_fixture(cs.cfg_energy_scaled(4096, 4.0), ref_f64.plan_energy_scaled(4096, 4.0), 1, 0xC0FFEE + 2, 4096, "energy4096.npz")
-    welch_fixture("welch1024.npz")
+    # cfg3 / the reference engine's own configuration: whole frames, and the radio's packet lengths (364 and 363 samples at MTU 1500 with
+    # sc16 / fc32 on the wire — SURVEY.md §8 row a2 — and a short 100-sample packet)
+    for L in (512, 364, 363, 100):
+        seeded_fixture(cs.cfg_reference(), ref_f64.plan_reference(), cycle, 0xC0FFEE + 4 + L, L, f"seeded_ref512_L{L}.npz", cfg_name="ref512")
+    # cfg0 / cfg1 (1024 points) and the headline (4096 points x 3 channels): energy detect, threshold relative to the noise-floor band
+    seeded_fixture(cs.cfg_energy_scaled(1024, 4.0), ref_f64.plan_energy_scaled(1024, 4.0), cycle, 0xC0FFEE + 1, 1024, "seeded_energy1024.npz", cfg_name="energy1024")
+    seeded_fixture(cs.cfg_energy_scaled(4096, 4.0), ref_f64.plan_energy_scaled(4096, 4.0), cycle, 0xC0FFEE + 2, 4096, "seeded_energy4096.npz", cfg_name="energy4096")
+    # cfg2: 4096-point Welch x 64 bands as worded, and its 1024-point twin
+    welch_seeded("seeded_welch4096.npz", 4096)
+    welch_seeded("seeded_welch1024.npz", 1024)
     ann_fixture()
     kat_fixture()
     print(sorted(os.listdir(HERE)))

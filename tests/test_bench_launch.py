@@ -17,6 +17,19 @@ def _load_bench():
     return mod
 
 
+def failure_reports(stderr):
+    """The `{"bench_failure": {...}}` objects failing ranks wrote to stderr (bench.py: fail_report), one per line."""
+    out = []
+    for ln in stderr.splitlines():
+        ln = ln.strip()
+        if ln.startswith('{"bench_failure"'):
+            out.append(json.loads(ln)["bench_failure"])
+    return out
+
+
+FAILURE_KEYS = {"failed_stage", "rank", "world", "elapsed_s", "why", "rccl", "visible_devices", "pci_bus_id", "device"}
+
+
 def test_self_launch_command_and_relay(monkeypatch, capsys):
     bench = _load_bench()
     seen = {}
@@ -93,6 +106,30 @@ def test_two_self_launched_ranks_reach_the_gpu_check_without_a_gpu():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout
     assert "needs a GPU" in r.stderr
+    # every failing rank of an N > 1 job names itself, the stage and what it could see, as one JSON object on stderr
+    reps = failure_reports(r.stderr)
+    # (the launcher stops the other rank as soon as the first one has failed: one report or two)
+    assert reps and {f["rank"] for f in reps} <= {0, 1} and len({f["rank"] for f in reps}) == len(reps), r.stderr[-2000:]
+    for f in reps:
+        assert set(f) == FAILURE_KEYS and f["world"] == 2 and f["failed_stage"] == "start" and "needs a GPU" in f["why"]
+        assert f["rccl"] is None and f["pci_bus_id"] is None and f["elapsed_s"] >= 0
+        assert f["visible_devices"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"      # (self_launch exports it for the ranks)
+
+
+def test_failure_report_is_silent_at_n_1_and_one_line_otherwise(capfd):
+    bench = _load_bench()
+    bench.RUN.update(world=1, multi=False)
+    bench.fail_report("anything")
+    assert capfd.readouterr().err == ""
+    bench.RUN.update(world=8, rank=5, multi=True, stage="communicator (ncclCommInitRank is collective)", device=5, devices_seen=8,
+                     pci_bus_id="0000:c5:00.0", rccl={"nranks": 8, "rank": 5, "pci_bus_id": "0000:c5:00.0"})
+    bench.fail_report("CrnError: ncclCommInitRank: unhandled system error")
+    err = capfd.readouterr().err
+    assert err.count("\n") == 1
+    (f,) = failure_reports(err)
+    assert set(f) == FAILURE_KEYS and f["rank"] == 5 and f["world"] == 8 and f["failed_stage"].startswith("communicator")
+    assert f["rccl"]["nranks"] == 8 and f["pci_bus_id"] == "0000:c5:00.0" and f["visible_devices"]["device_count"] == 8
+    assert "ncclCommInitRank" in f["why"]
 
 
 def test_watchdog_ends_a_rank_stuck_in_a_stage():
@@ -101,10 +138,13 @@ def test_watchdog_ends_a_rank_stuck_in_a_stage():
     code = ("import importlib.util, time\n"
             f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r})\n"
             "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.RUN.update(world=4, rank=3)\n"
             "d = b.Watchdog(0.5, 3)\n"
             "d.pet('first'); time.sleep(0.2); d.pet('the stage that hangs'); time.sleep(30)\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 6 and "rank 3" in r.stderr and "the stage that hangs" in r.stderr
+    (f,) = failure_reports(r.stderr)
+    assert f["failed_stage"] == "the stage that hangs" and f["rank"] == 3 and f["world"] == 4 and "watchdog" in f["why"] and f["elapsed_s"] >= 0.5
     code = code.replace("time.sleep(30)", "d.stop(); time.sleep(1.5)")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr

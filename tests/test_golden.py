@@ -1,5 +1,8 @@
 """Committed fixtures (tests/golden/, written by make_golden.py from tests/ref_f64.py — the independent
-float64 restatement of SURVEY.md Appendix A, which shares no code with oracle/ or the product).
+float64 restatement of SURVEY.md Appendix A, which shares no code with oracle/ or the product).  Every BASELINE.json
+configuration is pinned at its own size: the reference engine's (512 points, whole frames and 364 / 363 / 100-sample
+packets), 1024- and 4096-point energy detect (8 epochs each: idle and every channel), and the 64-band Welch PSD at 1024
+and at 4096 points.
 
 CPU: the fixtures are re-derived by ref_f64 (the generator must stay reproducible), the C oracle
 must agree with them, SURVEY.md Appendix C's probe values must come out of both, and the product's
@@ -21,6 +24,7 @@ import pytest
 import crnsense as cs
 import oracle_py as orc
 import ref_f64
+import signals
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -36,28 +40,61 @@ def floor_gpu(cfg):
     return 1e-3 if cfg.fft_len <= 1024 else 1e-2
 
 
-def _welch1024():
-    g = np.load(os.path.join(GOLD, "welch1024.npz"))
-    cfg = cs.cfg_welch(1024, 8, 64)
-    for b in range(64):
-        cfg.thresh[b] = float(g["thresh"][b])
-    return cfg, ref_f64.plan_welch(1024, 8, 64, g["thresh"])
+def _ref():
+    return cs.cfg_reference(), ref_f64.plan_reference()
 
 
-CASES = [("ref512_L364.npz", lambda: (cs.cfg_reference(), ref_f64.plan_reference())),
-         ("ref512_L512.npz", lambda: (cs.cfg_reference(), ref_f64.plan_reference())),
-         ("energy1024.npz", lambda: (cs.cfg_energy_scaled(1024, 4.0), ref_f64.plan_energy_scaled(1024, 4.0))),
-         ("energy4096.npz", lambda: (cs.cfg_energy_scaled(4096, 4.0), ref_f64.plan_energy_scaled(4096, 4.0))),
-         ("welch1024.npz", _welch1024)]
+def _energy(n):
+    return lambda g: (cs.cfg_energy_scaled(n, 4.0), ref_f64.plan_energy_scaled(n, 4.0))
 
 
-def per_bin_err(spec, truth, floor):
-    lim = np.maximum(truth, floor * truth.mean(axis=1, keepdims=True))
+def _welch(n):
+    def mk(g):
+        cfg = cs.cfg_welch(n, 8, 64)
+        for b in range(64):
+            cfg.thresh[b] = float(g["thresh"][b])
+        return cfg, ref_f64.plan_welch(n, 8, 64, g["thresh"])
+    return mk
+
+
+# Every BASELINE.json configuration at its own size.  "seeded_*" files hold the recipe of the input (seed, L, picks)
+# and the float64 outputs; ref512_L364.npz carries its IQ (the generator guard below, and what smoke() reads on the GPU box).
+CASES = [("ref512_L364.npz", lambda g: _ref()),                     # cfg3 on the radio's packets, IQ stored
+         ("seeded_ref512_L512.npz", lambda g: _ref()),              # cfg3: the reference engine's own configuration, whole frames
+         ("seeded_ref512_L364.npz", lambda g: _ref()),              # ... and the packet lengths SURVEY.md §8 row a2 names
+         ("seeded_ref512_L363.npz", lambda g: _ref()),
+         ("seeded_ref512_L100.npz", lambda g: _ref()),
+         ("seeded_energy1024.npz", _energy(1024)),                  # cfg0 / cfg1
+         ("seeded_energy4096.npz", _energy(4096)),                  # the headline: 8 epochs, idle + each channel twice
+         ("seeded_welch1024.npz", _welch(1024)),
+         ("seeded_welch4096.npz", _welch(4096))]                    # cfg2 as worded: Hann, hop 2048, K = 8, 64 bands, f32 thresholds
+
+
+def load_case(name, mk):
+    """(cfg, plan, fixture, iq, n_epochs, L): the IQ from the file, or regenerated from the recorded recipe and checked against the
+    recorded energy (a change of numpy's generator or of signals.make_epochs must not pass as a numerical regression of the path)."""
+    g = np.load(os.path.join(GOLD, name))
+    cfg, plan = mk(g)
+    n, L = int(g["decision"].size), int(g["L"])
+    if "iq" in g.files:
+        return cfg, plan, g, g["iq"], n, L
+    iq, _ = signals.make_epochs(cfg, n, seed=int(g["seed"]), L=L, picks=g["picks"])
+    l2 = float(np.sum(iq.astype(np.float64) ** 2))
+    assert abs(l2 / float(g["iq_l2"]) - 1) < 1e-9, f"{name}: signals.make_epochs no longer reproduces the recorded input (energy {l2} vs {float(g['iq_l2'])})"
+    return cfg, plan, g, iq, n, L
+
+
+def per_bin_err(spec, truth, floor, mean=None):
+    mean = truth.mean(axis=1, keepdims=True) if mean is None else np.asarray(mean)[:, None]
+    lim = np.maximum(truth, floor * mean)
     return (np.abs(spec - truth) / lim).max()
 
 
 def check_against_golden(got, g, cfg, floor):
-    assert per_bin_err(got["spectrum"], g["spectrum_f64"], floor) < 1e-5
+    if "spectrum_f64" in g.files:
+        assert per_bin_err(got["spectrum"], g["spectrum_f64"], floor) < 1e-5
+    else:   # a seeded fixture keeps 64 bins (the 16 strongest + 48 evenly spaced) and the mean over all bins for the floor
+        assert per_bin_err(got["spectrum"][:, g["spectrum_bins"]], g["spectrum_sel_f64"], floor, g["spectrum_mean_f64"]) < 1e-5
     rel = np.abs(got["features"] - g["features_f64"]) / np.maximum(np.abs(g["features_f64"]), 1e-300)
     assert rel.max() < 1e-5, rel.max()
     assert np.array_equal(got["decision"], g["decision"])
@@ -66,38 +103,59 @@ def check_against_golden(got, g, cfg, floor):
         assert np.abs(got["ann_out"] - g["ann_out_f64"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name,mk", CASES)
+def test_fixture_directory_is_small_and_covers_every_configuration():
+    size = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    assert size <= 512 * 1024, size
+    assert sorted(f for f in os.listdir(GOLD) if f.endswith(".npz")) == sorted([c[0] for c in CASES] + ["ann_table.npz"])
+    g = np.load(os.path.join(GOLD, "seeded_energy4096.npz"))
+    assert g["decision"].size >= 8 and set(g["picks"].tolist()) == {0, 1, 2, 3}      # idle + each channel
+    assert np.array_equal(g["occupancy"][np.arange(8), np.maximum(g["picks"], 1)], (g["picks"] > 0).astype(np.uint8))
+    g = np.load(os.path.join(GOLD, "seeded_welch4096.npz"))
+    assert g["decision"].size >= 4 and g["thresh"].dtype == np.float32 and g["thresh"].size == 64
+    for L in (364, 363, 100):
+        assert int(np.load(os.path.join(GOLD, f"seeded_ref512_L{L}.npz"))["L"]) == L
+
+
+def test_generator_still_reproduces_the_stored_iq():
+    """The guard the seeded fixtures rest on: signals.make_epochs(seed) gives the samples ref512_L364.npz was written with (bit for bit
+    here; to one fp32 ulp on a host whose libm differs), so the recipes in the seeded files mean the inputs they were computed from."""
+    g = np.load(os.path.join(GOLD, "ref512_L364.npz"))
+    iq, picks = signals.make_epochs(cs.cfg_reference(), g["decision"].size, seed=0xC0FFEE, L=int(g["L"]))
+    assert np.array_equal(picks, g["picks"])
+    assert np.allclose(iq, g["iq"], rtol=2e-7, atol=1e-12) and (iq != g["iq"]).mean() < 1e-4
+
+
+@pytest.mark.parametrize("name,mk", CASES, ids=[c[0][:-4] for c in CASES])
 def test_fixture_is_what_the_independent_reference_computes(built, name, mk):
     """make_golden.py is reproducible, and no fixture epoch sits near a decision boundary."""
-    g = np.load(os.path.join(GOLD, name))
-    cfg, plan = mk()
-    n = g["decision"].size
-    again = ref_f64.run(plan, g["iq"], n, L=int(g["L"]))
-    assert np.allclose(again["spectrum"], g["spectrum_f64"], rtol=1e-12, atol=0)
-    assert np.allclose(again["features"], g["features_f64"], rtol=1e-12, atol=0)
-    assert np.array_equal(again["decision"], g["decision"])
+    cfg, plan, g, iq, n, L = load_case(name, mk)
+    again = ref_f64.run(plan, iq, n, L=L)
+    if "spectrum_f64" in g.files:
+        assert np.allclose(again["spectrum"], g["spectrum_f64"], rtol=1e-12, atol=0)
+    else:
+        assert np.allclose(again["spectrum"][:, g["spectrum_bins"]], g["spectrum_sel_f64"], rtol=1e-10, atol=0)
+        assert np.allclose(again["spectrum"].mean(axis=1), g["spectrum_mean_f64"], rtol=1e-10, atol=0)
+    assert np.allclose(again["features"], g["features_f64"], rtol=1e-10, atol=0)
+    assert np.array_equal(again["decision"], g["decision"]) and np.array_equal(again["occupancy"], g["occupancy"])
     assert (g["margin"] > (1e-3 if plan.decide == "ann" else 1e-4)).all()
     if plan.decide == "ann":
         assert np.array_equal(g["decision"], g["picks"])   # decisions = the channels the input drives
 
 
-@pytest.mark.parametrize("name,mk", CASES)
+@pytest.mark.parametrize("name,mk", CASES, ids=[c[0][:-4] for c in CASES])
 def test_oracle_matches_independent_golden(built, name, mk):
-    g = np.load(os.path.join(GOLD, name))
-    cfg, _ = mk()
-    n = g["decision"].size
-    got = orc.run(cfg, g["iq"], n, L=int(g["L"]), want_spectrum=True)
+    cfg, _, g, iq, n, L = load_case(name, mk)
+    got = orc.run(cfg, iq, n, L=L, want_spectrum=True)
     check_against_golden(got, g, cfg, FLOOR_ORACLE)
 
 
 def test_literal_reference_epoch_matches_independent_golden(built):
     """crn_oracle_ref_epoch is the line-by-line form of CE_Predictive_Node.cpp:146-289 (fixed arrays of
     512, the five loops as written); it must land on the float64 values too."""
-    for name in ("ref512_L364.npz", "ref512_L512.npz"):
-        g = np.load(os.path.join(GOLD, name))
-        L = int(g["L"])
-        for e in range(g["decision"].size):
-            r = orc.ref_epoch(g["iq"][e * 10 * L * 2:(e + 1) * 10 * L * 2], L)
+    for name in ("ref512_L364.npz", "seeded_ref512_L512.npz", "seeded_ref512_L363.npz", "seeded_ref512_L100.npz"):
+        _, _, g, iq, n, L = load_case(name, lambda g: _ref())
+        for e in range(n):
+            r = orc.ref_epoch(iq[e * 10 * L * 2:(e + 1) * 10 * L * 2], L)
             assert r["decision"] == g["decision"][e]
             assert np.allclose(r["features"], g["features_f64"][e], rtol=1e-5, atol=0)
             assert np.abs(r["ann_out"] - g["ann_out_f64"][e]).max() < 1e-6
@@ -192,15 +250,20 @@ def test_cfg_helpers_describe_the_independent_plans(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,mk", CASES)
+@pytest.mark.parametrize("name,mk", CASES, ids=[c[0][:-4] for c in CASES])
 def test_gpu_matches_independent_golden(built, name, mk):
-    g = np.load(os.path.join(GOLD, name))
-    cfg, _ = mk()
-    n = g["decision"].size
+    cfg, _, g, iq, n, L = load_case(name, mk)
     s = cs.Sensor(cfg)
-    got = s.run_host(g["iq"], n, L=int(g["L"]), want_spectrum=True)
+    got = s.run_host(iq, n, L=L, want_spectrum=True)
     s.close()
     check_against_golden(got, g, cfg, floor_gpu(cfg))
+    # ... and the launch a caller who wants no spectrum gets (at 4096 points with the reference channel plan: the row-pruned kernel the
+    # headline runs) lands on the same float64 features and the same decisions
+    s = cs.Sensor(cfg)
+    fast = s.run_host(iq, n, L=L)
+    s.close()
+    rel = np.abs(fast["features"] - g["features_f64"]) / np.maximum(np.abs(g["features_f64"]), 1e-300)
+    assert rel.max() < 1e-5 and np.array_equal(fast["decision"], g["decision"]) and np.array_equal(fast["occupancy"], g["occupancy"])
 
 
 @pytest.mark.gpu
