@@ -507,7 +507,9 @@ CRN_API int crn_noise_floor_device(crn_handle *h, const float *d_features, int64
  * pinned memory of the handle's own, one slot per update: the asynchronous copy never reads memory a later call rewrites).
  * Updates (this call, crn_sense_set_ann, crn_sense_calibrate_thresholds) cannot be captured into a hipGraph — a replay would upload
  * whatever the reused staging slot holds by then: on a stream that is capturing they return CRN_ERR_STATE and enqueue nothing.
- * Launches capture fine. */
+ * Launches capture fine.  With all eight staging slots still in flight an update waits for the oldest with the handle's lock released
+ * (a launch on another thread never waits for an update's copy); if a crn_sense_set_bands on another thread changed the number of
+ * bands (or the decision rule) in that window the update returns CRN_ERR_STATE and writes nothing. */
 CRN_API int crn_sense_set_thresholds(crn_handle *h, const float *thresh, int32_t n_bands, void *stream);
 
 /* Allocate, now, what crn_noise_floor_host and crn_sense_calibrate_thresholds need (pinned + device upload buffers for 4096 epochs
@@ -559,8 +561,8 @@ CRN_API int crn_sense_get_stats(crn_handle *h, crn_sense_stats *out);
  * overlapped frames) run the sensing kernel in its dealt-frame form: one epoch per workgroup, its frames_per_epoch frames spread over the workgroup's lane
  * groups (8 at 512 points, 4 at 1024) instead of run one after the other by one of them, the K-frame accumulate replayed in frame
  * order afterwards: the same operations in the same order, so every output is bit for bit what the streaming form gives, in about
- * ceil(K / groups) frame latencies instead of K.  Chosen per launch from n_epochs; *n = how many launches of this handle ran that
- * form.  (crn_sense_set_variant 400 / 401 / 402: automatic / never / at any batch size — for measurements and the equality test.) */
+ * ceil(K / groups) frame latencies instead of K.  Chosen per launch from n_epochs; *n = how many launches of this handle RAN that
+ * form (a launch the device refused the dealt form's LDS for runs the streaming form and is not counted).  (crn_sense_set_variant 400 / 401 / 402: automatic / never / at any batch size — for measurements and the equality test.) */
 CRN_API int crn_sense_dealt_launches(crn_handle *h, int64_t *n);
 
 /* Name, registers and LDS of the sensing kernel selected for this handle. */

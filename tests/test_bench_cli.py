@@ -158,7 +158,7 @@ def test_bench_two_ranks_on_one_gpu_through_a_stand_in_rccl(built):
         out = _run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
                           "--epochs", "2048", "--cpu-epochs", "32", *extra], 300, env, cwd=ROOT)
-        assert out.returncode == 0, out.stderr[-3000:]
+        assert out.returncode == 0, _why(out.stderr)
         lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
         assert len(lines) == 1, out.stdout[-2000:]
         d = json.loads(lines[0])
@@ -179,6 +179,13 @@ def _check_cpu_baseline_of_an_n_gt_1_line(d, n):
     assert "not re-measured at N > 1" in (d["roofline"]["traffic_source"] or "not re-measured at N > 1")
 
 
+def _why(stderr):
+    """What a failed N > 1 run said: the ranks' own failure objects and watchdog lines first (they name the stage), then the tail."""
+    from test_bench_launch import failure_reports
+    said = [ln for ln in stderr.splitlines() if "did not finish within" in ln or ln.startswith("sharding:") or ln.startswith("bench")]
+    return json.dumps(failure_reports(stderr)) + "\n" + "\n".join(said[-16:]) + "\n" + stderr[-3000:]
+
+
 def _self_launched(n, *extra, epochs="512", timeout=600, cpu_epochs="0"):
     """`python bench.py --gpus n` with NO launcher and no WORLD_SIZE in the environment — the shape of the driver's single-GPU command
     at n > 1 — on the one GPU of the box, the ranks over tests/harness/libfake_rccl_mp.so."""
@@ -187,9 +194,10 @@ def _self_launched(n, *extra, epochs="512", timeout=600, cpu_epochs="0"):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(CRN_RCCL_LIB=fake, HIP_VISIBLE_DEVICES="0")
     from test_comm import _run_group
+    # (--stage-timeout 90: these runs take 5 - 30 s in all; a rank that hangs must cost the suite a minute and a half, not five)
     out = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
-                      "--epochs", epochs, "--cpu-epochs", cpu_epochs, *extra], timeout, env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
+                      "--epochs", epochs, "--cpu-epochs", cpu_epochs, "--stage-timeout", "90", *extra], timeout, env, cwd=ROOT)
+    assert out.returncode == 0, _why(out.stderr)
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-2000:]          # the parent relays exactly rank 0's line
     return json.loads(lines[0])
@@ -201,6 +209,7 @@ def test_bench_self_launches_two_ranks_without_a_launcher(built):
     assert "crn_comm_" in d["config"]["parallelism"] and d["config"]["rccl"]["nranks"] == 2
 
 
+@pytest.mark.gpu_first
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 @pytest.mark.parametrize("mode", [[], ["--mode", "scan"]])
 def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode, scaling):
@@ -209,11 +218,13 @@ def test_bench_cfg4_rehearsal_eight_self_launched_ranks_on_one_gpu(built, mode, 
     rank 0 through the C ABI, streams sharded eight ways, crn_comm_* slots, the barriers and the max-over-ranks timing; EVERY rank
     checks that its own block sits unchanged at its place in the gathered vector (a mismatch on any rank makes the launcher, and so
     the parent, exit non-zero) and rank 0's single JSON line is relayed."""
-    # weak: 1024 epochs on every rank.  strong: 8192 epochs in all, split eight ways — a share far below 4 GiB, so every rank
-    # alternates its launches between two streams (four exchange slots)
-    d = _self_launched(8, *mode, "--scaling", scaling, epochs="1024" if scaling == "weak" else "8192", cpu_epochs="32")
-    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["epochs_per_gpu"] == 1024
-    assert d["config"]["epochs_per_step_all_gpus"] == 8192 and d["config"]["streams_per_gpu"] == (2 if scaling == "strong" else 1)
+    # weak: 4096 epochs on every rank.  strong: 32 768 epochs in all, split eight ways — a share far below 4 GiB, so every rank
+    # alternates its launches between two streams (four exchange slots).  (Eight rank processes are all the GPU schedules at once:
+    # the test is marked gpu_first so that this pytest process is not a ninth — tests/conftest.py — and the batch is large enough
+    # that the ~50 ms clock-ramp top-up is ~200 lock-step gathers, not ~900, should a ninth process be there all the same.)
+    d = _self_launched(8, *mode, "--scaling", scaling, epochs="4096" if scaling == "weak" else "32768", cpu_epochs="32")
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["epochs_per_gpu"] == 4096
+    assert d["config"]["epochs_per_step_all_gpus"] == 32768 and d["config"]["streams_per_gpu"] == (2 if scaling == "strong" else 1)
     assert d["config"]["parallelism"].startswith("stream-sharded x8") and "crn_comm_" in d["config"]["parallelism"]
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 4
     _check_cpu_baseline_of_an_n_gt_1_line(d, 8)       # every N > 1 line carries the CPU figure (rank 0 measures it after the timed region)
@@ -314,7 +325,7 @@ def test_bench_two_real_rccl_ranks_on_one_gpu_are_refused_not_hung(built):
     assert len({f["pci_bus_id"] for f in reps}) == 1
     d = os.environ.get("CRN_EVIDENCE_DIR")
     if d and os.path.isdir(d):
-        msg = [ln for ln in out.stderr.splitlines() if "ncclCommInitRank" in ln]
+        msg = [ln for ln in out.stderr.splitlines() if "ncclCommInitRank" in ln and not ln.lstrip().startswith("{")]
         open(os.path.join(d, "two_real_rccl_ranks_one_gpu.txt"), "w").write(
             f"bench.py --gpus 2 with the real RCCL on one GPU: exit {out.returncode} after {took:.1f} s, no JSON line\n" + "\n".join(msg[:4]) + "\n"
             + "\n".join(json.dumps({"bench_failure": f}) for f in reps) + "\n")
