@@ -148,3 +148,17 @@ def test_watchdog_ends_a_rank_stuck_in_a_stage():
     code = code.replace("time.sleep(30)", "d.stop(); time.sleep(1.5)")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
+
+
+def test_eight_rank_rehearsals_are_collected_ahead_of_everything_that_opens_the_device():
+    """tests/conftest.py moves the gpu_first tests (eight rank processes on the one GPU) to the front of ANY selection, so that the pytest
+    process — which opens the device in its first in-process GPU test — is never a ninth GPU process beside them
+    (profiles/r06_nine_gpu_processes.txt).  Here: files named in the opposite order."""
+    r = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_zz_roofline_floors.py"), os.path.join(ROOT, "tests", "test_golden.py"),
+                        os.path.join(ROOT, "tests", "test_bench_cli.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    ids = [ln for ln in r.stdout.splitlines() if "::" in ln]
+    assert r.returncode == 0 and len(ids) > 20, r.stdout[-2000:] + r.stderr[-2000:]
+    first = [i for i in ids if "cfg4_rehearsal_eight_self_launched_ranks" in i]
+    assert len(first) == 4 and ids[:4] == first, ids[:8]
+    assert "test_zz_roofline_floors" in ids[4]           # the rest keeps the order it was given
