@@ -240,6 +240,32 @@ def test_band_edges_on_gpu(built):
     assert np.array_equal(got["decision"], want["decision"])
 
 
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_band_edges_of_the_scaled_plans_on_gpu(built, n):
+    """tests/test_oracle.py's sweep over every run's lo - 1 / lo / hi - 1 / hi at 1024 and 4096 points (incl. the scaled bin-511 gap),
+    through the HIP path twice: with the spectrum (full kernels) and without (the launch the headline makes: at 4096 points the kernel
+    pruned to the reference plan's rows) — the band that holds the tone reads N^2, every other band nothing."""
+    from test_oracle import scaled_edge_bins
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    edges = scaled_edge_bins(cfg)
+    t = np.arange(n)
+    x = np.stack([np.tile(np.exp(2j * np.pi * k * t / n), cfg.frames_per_epoch) for k, _ in edges]).astype(np.complex64)
+    iq = x.view(np.float32).ravel()
+    want = orc.run(cfg, iq, len(edges))
+    for want_spectrum in (True, False):
+        s = cs.Sensor(cfg)
+        got = s.run_host(iq, len(edges), want_spectrum=want_spectrum)
+        s.close()
+        for i, (k, band) in enumerate(edges):
+            for b in range(4):
+                if b == band:
+                    assert abs(got["features"][i, b] / float(n) ** 2 - 1) < 1e-5, (k, b, want_spectrum)
+                else:
+                    assert got["features"][i, b] < 1e-6 * float(n) ** 2, (k, b, want_spectrum)
+            if band:       # a channel's tone: that channel reads occupied (the empty bands hold rounding noise on both sides of their
+                assert got["occupancy"][i, band] == 1 and want["occupancy"][i, band] == 1      # compare: nothing is asserted of them)
+
+
 def test_all_zero_input_gives_all_busy(built):
     cfg = cs.cfg_reference()
     s = cs.Sensor(cfg)

@@ -26,14 +26,15 @@ def test_long_double_dft_matches_numpy(built, n):
     assert np.abs(orc.dft_f64(x) - np.fft.fft(x)).max() < 1e-11 * n
 
 
-def test_impulse_and_dc(built):
-    n = 512
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_impulse_and_dc(built, n):
+    """SURVEY.md §8(c) known answers at every size: a unit impulse has |X[k]| = 1 everywhere, DC lands in bin 0 with value N."""
     x = np.zeros(n, np.complex64)
     x[0] = 1
     assert np.allclose(orc.fft_radix2(x), np.ones(n), atol=0)  # exact: only additions of 0 and 1*t
     x[:] = 1
     y = orc.fft_radix2(x)
-    assert y[0] == n and np.abs(y[1:]).max() < 1e-4
+    assert y[0] == n and np.abs(y[1:]).max() < 1e-4 * (n / 512)
 
 
 def test_forward_sign(built):
@@ -86,6 +87,43 @@ def test_band_edges_single_tone(built, bin_, band):
         else:
             assert r["features"][b] < 1e-3
     assert abs(r["fft_avg"][bin_] - 512.0) < 1e-2
+
+
+def scaled_edge_bins(cfg):
+    """[(bin, band or None)]: for every run [lo, hi) of the band plan the bins lo - 1, lo, hi - 1, hi (mod N), each with the band that
+    holds it under the plan — derived from the plan's runs themselves, so that a neighbour which falls into another run is labelled so."""
+    n = cfg.fft_len
+    owner = {}
+    for s in range(cfg.n_segs):
+        g = cfg.segs[s]
+        for k in range(g.lo, g.hi):
+            owner[k] = g.band
+    bins = []
+    for s in range(cfg.n_segs):
+        g = cfg.segs[s]
+        for k in (g.lo - 1, g.lo, g.hi - 1, g.hi):
+            bins.append(k % n)
+    return [(k, owner.get(k)) for k in dict.fromkeys(bins)]
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_band_edges_of_the_scaled_plans(built, n):
+    """The same single-tone sweep at BASELINE's own sizes (cfg1: 1024 points, headline: 4096): the reference's runs scaled by N / 512
+    keep the gap below bin 0 — CH1's upper run ends 1 x N/512 bins short of N (the reference leaves out bin 511,
+    CE_Predictive_Node.cpp:177).  Energy mode: a unit on-bin tone puts N^2 into exactly its band's feature."""
+    cfg = cs.cfg_energy_scaled(n, 4.0)
+    edges = scaled_edge_bins(cfg)
+    s = n // 512
+    assert (n - s, None) in edges and (n - s - 1, 1) in edges and (16 * s, None) in edges and (0, 1) in edges   # the scaled 511 gap, CH1's ends
+    t = np.arange(n)
+    x = np.stack([np.tile(np.exp(2j * np.pi * k * t / n), cfg.frames_per_epoch) for k, _ in edges]).astype(np.complex64)
+    r = orc.run(cfg, x.view(np.float32).ravel(), len(edges))
+    for i, (k, band) in enumerate(edges):
+        for b in range(4):
+            if b == band:
+                assert abs(r["features"][i, b] / float(n) ** 2 - 1) < 1e-5, (k, b)
+            else:
+                assert r["features"][i, b] < 1e-6 * float(n) ** 2, (k, b, r["features"][i, b])
 
 
 def test_cascade_and_tx_mapping(built):
