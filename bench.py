@@ -36,9 +36,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 and one thread — the reference's own topology — BASELINE.md §3's protocol: 2 warm-up passes, median of 10.  At N > 1
                 rank 0 measures it after the timed region while the other ranks wait, so every 1 / 2 / 4 / 8-GPU line carries it.
 
+  config        batch_GiB, pruned_rows ("7/16": the kernel keeps the pass-3 rows the reference channel plan reaches; null = none pruned),
+                cfgH_as_worded_frac (= alt.cfgH_2GiB_batch.frac): the headline's conditions as fields; `workload` stays under 120 characters
+
 N > 1 is fail-fast: the gloo control plane and a per-stage watchdog on every rank share one limit (--stage-timeout, 300 s): a rank that
 dies or hangs — in gloo, inside RCCL, or waiting for the GPU — takes the job down with a non-zero exit within that time instead of
-holding the launcher until its own timeout.
+holding the launcher until its own timeout.  Every rank that fails says where in ONE JSON object on stderr (fail_report):
+{"bench_failure": {"failed_stage", "rank", "world", "elapsed_s", "why", "rccl": crn_comm_info or null, "visible_devices", "pci_bus_id", "device"}}.
 """
 import argparse
 import json
