@@ -154,13 +154,35 @@ class Watchdog:
                 os._exit(6)
 
 
+def run_ranks(cmd, env):
+    """Run the launcher: its stdout is collected (rank 0's JSON line is in it), its stderr goes straight through to ours as it comes — a
+    caller that kills a hung job still has everything said so far — while the ranks' `bench_failure` objects are remembered.
+    Returns (exit code, stdout text, [failure lines])."""
+    import subprocess
+    import threading
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, errors="replace")
+    failures = []
+
+    def pump():
+        for ln in p.stderr:
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+            if ln.lstrip().startswith('{"bench_failure"'):
+                failures.append(ln.strip())
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    out = p.stdout.read()
+    rc = p.wait()
+    t.join(timeout=10)
+    return rc, out, failures
+
+
 def self_launch(n):
     """`python bench.py --gpus N` started without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process (one rank per GPU; when the node
     shows fewer devices than ranks the ranks share device 0, which only a stand-in RCCL behind $CRN_RCCL_LIB accepts), pass on the
     one JSON line rank 0 prints, and return the launcher's exit code.  Called before anything in this process touches the GPU."""
     import socket
-    import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -169,17 +191,24 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")              # (what torch.distributed.run would set, without its warning)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
-    for ln in r.stdout.splitlines():
+    rc, out, failures = run_ranks(cmd, env)
+    lines = [ln for ln in out.splitlines() if ln.lstrip().startswith("{")]
+    for ln in out.splitlines():
         if ln not in lines and ln.strip():
             print(ln, file=sys.stderr)
     if lines:
         print(lines[-1], flush=True)
-    if r.returncode == 0 and not lines:
+    if rc != 0 and failures:
+        # the launcher's own summary (a screenful per job) comes after the ranks' one-line accounts: say them again, last, so that
+        # whoever keeps only the tail of this process's output still reads the cause
+        print(f"bench.py: the job failed (exit {rc}); what the failing rank(s) said, first failure first:", file=sys.stderr)
+        for ln in failures[:8]:
+            print(ln, file=sys.stderr)
+        sys.stderr.flush()
+    if rc == 0 and not lines:
         print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
         return 1
-    return r.returncode
+    return rc
 
 
 def live_counters(args, epochs, passes):

@@ -18,11 +18,13 @@ def _load_bench():
 
 
 def failure_reports(stderr):
-    """The `{"bench_failure": {...}}` objects failing ranks wrote to stderr (bench.py: fail_report), one per line."""
-    out = []
+    """The `{"bench_failure": {...}}` objects failing ranks wrote to stderr (bench.py: fail_report), one per line — each once: a
+    self-launching parent says them again at the end of its own stderr."""
+    out, seen = [], set()
     for ln in stderr.splitlines():
         ln = ln.strip()
-        if ln.startswith('{"bench_failure"'):
+        if ln.startswith('{"bench_failure"') and ln not in seen:
+            seen.add(ln)
             out.append(json.loads(ln)["bench_failure"])
     return out
 
@@ -34,15 +36,11 @@ def test_self_launch_command_and_relay(monkeypatch, capsys):
     bench = _load_bench()
     seen = {}
 
-    class R:
-        returncode = 0
-        stdout = "RCCL banner that a library printed\n" + json.dumps({"n_gpus": 8, "value": 1.0}) + "\n"
+    def fake_run(cmd, env):
+        seen["cmd"], seen["kw"] = cmd, {"env": env}
+        return 0, "RCCL banner that a library printed\n" + json.dumps({"n_gpus": 8, "value": 1.0}) + "\n", []
 
-    def fake_run(cmd, **kw):
-        seen["cmd"], seen["kw"] = cmd, kw
-        return R()
-
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "run_ranks", fake_run)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
     assert "torch" not in sys.modules or True     # (pytest plugins may have imported it; bench.py itself must not need it here)
     rc = bench.self_launch(8)
@@ -62,20 +60,33 @@ def test_self_launch_command_and_relay(monkeypatch, capsys):
 def test_self_launch_exit_codes(monkeypatch, capsys):
     bench = _load_bench()
 
-    class Fail:
-        returncode = 3
-        stdout = ""
-
-    class Silent:
-        returncode = 0
-        stdout = "no json here\n"
-
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
-    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: Fail())
+    monkeypatch.setattr(bench, "run_ranks", lambda cmd, env: (3, "", []))
     assert bench.self_launch(2) == 3
-    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: Silent())
+    monkeypatch.setattr(bench, "run_ranks", lambda cmd, env: (0, "no json here\n", []))
     assert bench.self_launch(2) == 1
     capsys.readouterr()
+
+
+def test_self_launch_repeats_the_ranks_failure_objects_last(monkeypatch, capfd):
+    """The launcher's own failure summary (dozens of lines per job) follows the ranks' one-line accounts: the parent passes stderr through
+    as it comes — nothing is held back from a caller that kills a hung job — and says the failure objects again at the very end."""
+    bench = _load_bench()
+    obj = json.dumps({"bench_failure": {"failed_stage": "communicator", "rank": 1, "world": 2, "why": "x"}})
+    child = ("import sys, time\n"
+             "sys.stderr.write('early line\\n'); sys.stderr.flush()\n"
+             f"sys.stderr.write({obj!r} + '\\n')\n"
+             "sys.stderr.write('launcher summary line\\n' * 50)\n"
+             "print('not json'); sys.exit(5)\n")
+    rc, out, failures = bench.run_ranks([sys.executable, "-c", child], dict(os.environ))
+    assert rc == 5 and out.strip() == "not json" and failures == [obj]
+    err = capfd.readouterr().err
+    assert err.startswith("early line") and err.count("launcher summary line") == 50 and obj in err
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setattr(bench, "run_ranks", lambda cmd, env: (5, "not json\n", [obj]))
+    assert bench.self_launch(2) == 5
+    err = capfd.readouterr().err
+    assert err.rstrip().splitlines()[-1] == obj and "what the failing rank(s) said" in err
 
 
 def test_main_self_launches_before_any_gpu_or_torch_use(monkeypatch):
@@ -114,6 +125,8 @@ def test_two_self_launched_ranks_reach_the_gpu_check_without_a_gpu():
         assert set(f) == FAILURE_KEYS and f["world"] == 2 and f["failed_stage"] == "start" and "needs a GPU" in f["why"]
         assert f["rccl"] is None and f["pci_bus_id"] is None and f["elapsed_s"] >= 0
         assert f["visible_devices"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"      # (self_launch exports it for the ranks)
+    # ... and the parent says the objects again after the launcher's own summary: the last line of stderr is one of them
+    assert r.stderr.rstrip().splitlines()[-1].startswith('{"bench_failure"') and "ChildFailedError" in r.stderr
 
 
 def test_failure_report_is_silent_at_n_1_and_one_line_otherwise(capfd):
