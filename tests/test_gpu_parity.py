@@ -631,6 +631,68 @@ def test_full_size_batch_properties(built):
     s.close()
 
 
+def test_headline_size_batch_properties(built):
+    """The batch bench.py's headline runs — 28 672 epochs x 10 x 4096-pt = 8.75 GiB, generated in HBM — through properties that need no
+    oracle at that size:
+      * the occupancy of EVERY epoch is the driven pattern;
+      * the kernel pruned to the reference plan's rows (what the headline launches) and the full kernel (variant 2) give bit-identical
+        features and occupancy for all 28 672 epochs;
+      * results do not depend on how a batch is cut into launches (the launch geometry — epoch groups per workgroup, the short tail
+        workgroups — is chosen from the batch size): the whole batch in one launch equals, bit for bit, two halves and a ragged
+        three-way split launched separately;
+      * the first 32 epochs of the same bytes against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 28672
+    cfg = cs.cfg_energy_scaled(4096, 4.0)
+    spe = cs.samples_per_epoch(cfg)
+    iq = torch.zeros(E * spe * 2, dtype=torch.float32, device=dev)
+    truth = torch.zeros(E, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch(sensor, first, count, feats, occ):
+        sensor.run_device(iq.data_ptr() + first * spe * 8, count, 4096,
+                          {"features": feats.data_ptr() + first * 4 * 4, "ann_out": 0, "decision": 0, "occupancy": occ.data_ptr() + first * 4,
+                           "spectrum": 0}, stream=stream)
+
+    def outputs():
+        return torch.zeros(E, 4, dtype=torch.float32, device=dev), torch.zeros(E, 4, dtype=torch.uint8, device=dev)
+
+    s = cs.Sensor(cfg)
+    assert "PASS3_ROWS" in s.kernel_info()["name"]
+    s.synth_fill_device(iq.data_ptr(), E, spe, seed=1234, truth_ptr=truth.data_ptr(), stream=stream)
+    f_one, o_one = outputs()
+    launch(s, 0, E, f_one, o_one)
+    torch.cuda.synchronize()
+    picked = truth.cpu().numpy()
+    o = o_one.cpu().numpy()
+    want = np.zeros_like(o)
+    idx = np.nonzero(picked > 0)[0]
+    want[idx, picked[idx]] = 1
+    assert np.array_equal(o, want) and len(set(picked.tolist())) == 4
+    # cut into launches of other sizes (other geometries): the same bytes out
+    for cuts in ([0, E // 2, E], [0, 9001, 9001 + 257, E]):
+        f_cut, o_cut = outputs()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            launch(s, a, b - a, f_cut, o_cut)
+        torch.cuda.synchronize()
+        assert torch.equal(f_cut, f_one) and torch.equal(o_cut, o_one), cuts
+    # the full kernel on the whole batch
+    full = cs.Sensor(cfg)
+    full.set_variant(2)
+    assert "PASS3_ROWS" not in full.kernel_info()["name"]
+    f_full, o_full = outputs()
+    launch(full, 0, E, f_full, o_full)
+    torch.cuda.synchronize()
+    assert torch.equal(f_full, f_one) and torch.equal(o_full, o_one)
+    full.close()
+    n = 32
+    ref = orc.run(cfg, iq[: n * spe * 2].cpu().numpy(), n)
+    f1 = f_one[:n].cpu().numpy()
+    assert (np.abs(f1 - ref["features"]) / np.abs(ref["features"])).max() < FEATURE_TOL and np.array_equal(o[:n], ref["occupancy"])
+    s.close()
+
+
 def test_ingest_ring_many_streams(built):
     """The rx-worker side: packets of several streams arrive interleaved, the ring coalesces them
     into epochs, launches batches asynchronously and returns per-(stream, epoch) results that match
