@@ -693,6 +693,93 @@ def test_headline_size_batch_properties(built):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["cfg1_energy1024", "cfg2_welch4096"])
+def test_cfg1_and_cfg2_at_their_own_batch_size(built, name):
+    """BASELINE.json configs[1] and configs[2] at SURVEY.md §8(d)'s batch — 2^28 samples = 2 GiB of IQ generated in HBM (1024-pt x 3 ch:
+    26 214 epochs of 10 frames; 4096-pt Welch x 64 bands, Hann, hop 2048, K = 8: 16 383 epochs of one continuous stream, thresholds
+    lambda x the measured median band energy) — through properties that need no oracle at that size:
+      * every epoch's driven channel reads occupied (cfg1: and nothing else does);
+      * results do not depend on how the batch is cut into launches: one launch = two halves = a ragged three-way split, bit for bit
+        (Welch: a cut lands on an epoch boundary of the stream; the launches read across it into the same samples);
+      * cfg1: the kernel pruned to the reference plan's rows and the full kernel (variant 2) agree bit for bit on all epochs;
+      * x -> 2x multiplies every feature by exactly 4;
+      * the first 24 epochs of the same bytes against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    welch = name == "cfg2_welch4096"
+    cfg = cs.cfg_welch(4096, 8, 64) if welch else cs.cfg_energy_scaled(1024, 4.0)
+    nb = cfg.n_bands
+    spe = cs.samples_per_epoch(cfg)
+    E = (2 ** 28) // spe - (1 if welch else 0)      # (the overlapped stream needs half a frame beyond its last epoch)
+    n_samples = cs.samples_needed(cfg, E)
+    assert n_samples <= 2 ** 28 and n_samples > 2 ** 28 - 2 * spe
+    iq = torch.zeros(n_samples * 2, dtype=torch.float32, device=dev)
+    truth = torch.zeros(E, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    s = cs.Sensor(cfg)
+    sc = cs.SynthCfg()
+    sc.seed, sc.noise_power, sc.signal_rms, sc.tones_per_band = 4321, 1e-6, 0.02, 8
+    sc.pu_model, sc.signal_kind, sc.n_streams, sc.adc_bits = cs.PU_UNIFORM, cs.SIG_TONES, 1, 0
+    s.synth_fill_device_ex(iq.data_ptr(), E, spe, sc, truth_ptr=truth.data_ptr(), stream=stream)
+
+    def launch(sensor, first, count, feats, occ):
+        sensor.run_device(iq.data_ptr() + first * spe * 8, count, cfg.fft_len,
+                          {"features": feats.data_ptr() + first * nb * 4, "ann_out": 0, "decision": 0, "occupancy": occ.data_ptr() + first * nb,
+                           "spectrum": 0}, stream=stream)
+
+    def outputs():
+        return torch.zeros(E, nb, dtype=torch.float32, device=dev), torch.zeros(E, nb, dtype=torch.uint8, device=dev)
+
+    f_one, o_one = outputs()
+    launch(s, 0, E, f_one, o_one)
+    if welch:   # SURVEY.md §8(d) cfg2: thr_b = lambda x NF_est, NF_est = the median band energy of this very batch
+        nf = s.noise_floor(f_one.data_ptr(), E, stream=stream)
+        analytic = (4096 / 64) * 4096 * 1e-6 * 0.375
+        assert 0.8 * analytic < nf < 1.25 * analytic
+        s.set_thresholds([float(np.float32(4.0) * np.float32(nf))] * nb, stream=stream)
+        launch(s, 0, E, f_one, o_one)
+    torch.cuda.synchronize()
+    picked = truth.cpu().numpy()
+    o = o_one.cpu().numpy()
+    idx = np.nonzero(picked > 0)[0]
+    assert len(set(picked.tolist())) == (65 if welch else 4) and idx.size > E // 2      # idle and every channel occur
+    if welch:
+        assert (o[idx, picked[idx] - 1] == 1).all()          # (bands are channels 1..64: band b - 1 carries channel b's traffic)
+    else:
+        want = np.zeros_like(o)
+        want[idx, picked[idx]] = 1
+        assert np.array_equal(o, want)
+    for cuts in ([0, E // 2, E], [0, 5003, 5003 + 257, E]):
+        f_cut, o_cut = outputs()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            launch(s, a, b - a, f_cut, o_cut)
+        torch.cuda.synchronize()
+        assert torch.equal(f_cut, f_one) and torch.equal(o_cut, o_one), cuts
+    if not welch:
+        assert "PASS3_ROWS" in s.kernel_info()["name"]
+        full = cs.Sensor(cfg)
+        full.set_variant(2)
+        assert "PASS3_ROWS" not in full.kernel_info()["name"]
+        f_full, o_full = outputs()
+        launch(full, 0, E, f_full, o_full)
+        torch.cuda.synchronize()
+        assert torch.equal(f_full, f_one) and torch.equal(o_full, o_one)
+        full.close()
+    n = 24
+    ref = orc.run(s.cfg, iq[: cs.samples_needed(cfg, n) * 2].cpu().numpy(), n)
+    f1 = f_one[:n].cpu().numpy()
+    assert (np.abs(f1 - ref["features"]) / np.abs(ref["features"])).max() < FEATURE_TOL
+    rel_to_thr = np.abs(ref["features"] / np.array(s.cfg.thresh[:nb], np.float32) - 1) if welch else None
+    same = o[:n] == ref["occupancy"]
+    assert same.all() if not welch else same[rel_to_thr > pol.THRESHOLD_MARGIN].all()      # (outside the measured disagreement band: DESIGN.md §2)
+    iq.mul_(2.0)
+    f_two, o_two = outputs()
+    launch(s, 0, E, f_two, o_two)
+    torch.cuda.synchronize()
+    assert torch.equal(f_two, 4 * f_one)
+    s.close()
+
+
 def test_ingest_ring_many_streams(built):
     """The rx-worker side: packets of several streams arrive interleaved, the ring coalesces them
     into epochs, launches batches asynchronously and returns per-(stream, epoch) results that match
